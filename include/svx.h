@@ -1,0 +1,179 @@
+/*
+ * svx.h -- C ABI of libsvx: the MI355X (gfx950) implementation of Speech-Vecalign's
+ * segment-alignment hot path (svecalign/vecalign + svecalign/seg_align).
+ *
+ * The reference has exactly one native module on this path, svecalign/vecalign/dp_core.pyx
+ * (Cython, 5 functions), called from svecalign/vecalign/dp_utils.py:vecalign().  Each entry
+ * point below names the reference interface it replaces (paths relative to the reference
+ * repository).  All array arguments are DEVICE pointers (HIP) unless marked "host"; the caller
+ * owns every input and output buffer, the library owns only scratch inside the context.
+ * Everything is asynchronous on the context's stream; call svx_synchronize() (or synchronise
+ * the stream yourself) before reading results.  No function falls back to the CPU.
+ *
+ * Return value: 0 (SVX_OK) or an SVX_ERR_* code; svx_last_error() has the message.
+ */
+#ifndef SVX_H
+#define SVX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svx_ctx svx_ctx;
+
+enum svx_dtype { SVX_F32 = 0, SVX_F16 = 1, SVX_BF16 = 2 };
+
+enum svx_status {
+    SVX_OK = 0,
+    SVX_ERR_ARG = 1,       /* bad shape / null pointer / unsupported size (asserts of dp_core.pyx:48-60,186-190,216) */
+    SVX_ERR_OVERLAPS = 2,  /* "%d x overlaps requrested (via alignment_types), but vecs0 only has %d" dp_core.pyx:204-209 */
+    SVX_ERR_HIP = 3,       /* a HIP runtime call failed */
+    SVX_ERR_TRACEBACK = 4, /* 'traceback bug' dp_utils.py:123-124 / walked off the band */
+    SVX_ERR_NOMEM = 5,     /* scratch allocation failed */
+    SVX_ERR_EXTEND = 6,    /* 'asked to extend alignments but already bigger than requested' dp_utils.py:242-243 */
+    SVX_ERR_PATH = 7,      /* search path is not a unit-step lattice path from (0,0) */
+    SVX_ERR_BP = 8         /* 'got unknown value' dp_utils.py:166-167 */
+};
+
+#define SVX_MAX_LEVELS 16 /* pyramid depth limit (N*M <= max_size_full_dp^2 * 4^15) */
+#define SVX_MAX_TYPES 128 /* alignment types per call (a=10 -> 45) */
+#define SVX_MAX_DIM 2048  /* embedding dimension limit; d must be a multiple of 8 */
+
+/* ---- context -------------------------------------------------------------------------- */
+/* One context per (process, device): owns a HIP stream reference and a grow-only scratch arena.
+ * Replaces nothing in the reference (its module is stateless); see SURVEY.md section 8(b). */
+int svx_create(int device_id, svx_ctx **out);
+int svx_destroy(svx_ctx *ctx);
+/* Use an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream. */
+int svx_set_stream(svx_ctx *ctx, void *hip_stream);
+int svx_synchronize(svx_ctx *ctx);
+/* Message of the last failure on this context (ctx may be NULL for svx_create failures). */
+const char *svx_last_error(const svx_ctx *ctx);
+const char *svx_version(void);
+/* Bytes of device scratch currently held by the context. */
+int64_t svx_scratch_bytes(const svx_ctx *ctx);
+
+/* ---- the five native functions of dp_core.pyx (float32 buffers, like the reference) ----- */
+
+/* make_dense_costs(vecs0, vecs1, norm0, norm1, offset0, offset1) -> costs      dp_core.pyx:36-77
+ * vecs0 [k0][s0][d], vecs1 [k1][s1][d], norm0 [k0][s0], norm1 [k1][s1]; costs [s0][s1]. */
+int svx_dense_costs(svx_ctx *ctx, const float *vecs0, int k0, int s0, const float *vecs1, int k1, int s1, int d,
+                    const float *norm0, const float *norm1, int offset0, int offset1, float *costs);
+
+/* dense_dp(alignment_cost, pen) -> (csum, bp)                                   dp_core.pyx:79-141
+ * cost [s0][s1]; csum [s0+1][s1+1] float64 (may be NULL); bp [s0+1][s1+1] int32. */
+int svx_dense_dp(svx_ctx *ctx, const float *cost, int s0, int s1, float pen, double *csum, int32_t *bp);
+
+/* score_path(xx, yy, norm1, norm2, vecs1, vecs2, out)                            dp_core.pyx:143-161
+ * xx,yy [n] int32; norm1 [rows1], norm2 [rows2]; vecs1 [rows1][d], vecs2 [rows2][d]; out [n]. */
+int svx_score_path(svx_ctx *ctx, const int32_t *xx, const int32_t *yy, int64_t n, const float *norm1,
+                   const float *norm2, const float *vecs1, int rows1, const float *vecs2, int rows2, int d, float *out);
+
+/* make_sparse_costs(vecs0, vecs1, norms0, norms1, x_y_path, alignment_types, width_over2)
+ *   -> (a_b_feats, b_offset)                                                    dp_core.pyx:165-267
+ * path [A][2] int32 (device), types [T][2] int32 (HOST); costs [T][A][2W]; b_offset [A]. */
+int svx_sparse_costs(svx_ctx *ctx, const float *vecs0, int k0, int xsize, const float *vecs1, int k1, int ysize,
+                     int d, const float *norms0, const float *norms1, const int32_t *path, int A,
+                     const int32_t *types_host, int T, int width_over2, float *costs, int32_t *b_offset);
+
+/* sparse_dp(a_b_costs, b_offset_in, alignment_types, del_penalty, x_in_size, y_in_size)
+ *   -> (a_b_csum, a_b_xp, a_b_yp, b_offset_out)                                 dp_core.pyx:269-404
+ * costs [T][A][B]; csum [A+2][B] float64; xp, yp [A+2][B] int32; b_offset_out [A+2]. */
+int svx_sparse_dp(svx_ctx *ctx, const float *costs, const int32_t *b_offset_in, int A, int B,
+                  const int32_t *types_host, int T, double del_penalty, int x_in_size, int y_in_size,
+                  double *csum, int32_t *xp, int32_t *yp, int32_t *b_offset_out);
+
+/* ---- device versions of the numpy-side hot spots of dp_utils.py ------------------------ */
+
+/* make_norm1(vecs): rows /= (||row|| + 1e-5), in place                          dp_utils.py:32-40 */
+int svx_make_norm1(svx_ctx *ctx, float *vecs, int64_t rows, int d);
+
+/* downsample_vectors(vecs) -> half [k][n/2][d]                                  dp_utils.py:362-378 */
+int svx_downsample(svx_ctx *ctx, const float *vecs, int k, int n, int d, float *half);
+
+/* compute_norms(vecs0, vecs1, num_samples) -> norms0 [k0][n0]                   dp_utils.py:326-359
+ * The random row indices (one np.random.choice per overlap layer of vecs1, dp_utils.py:345-348)
+ * are drawn by the caller: idx [k1][samples_per_overlap] int32, indices into vecs1's rows. */
+int svx_compute_norms(svx_ctx *ctx, const float *vecs0, int k0, int n0, const float *vecs1, int k1, int n1, int d,
+                      const int32_t *idx, int samples_per_overlap, float *norms0);
+
+/* DeletionKnob(samp, 0, max(samp)).percentile_frac_to_del_penalty(frac)  dp_utils.py:43-79,312-313,321
+ * scores [n] float32 -> *del_penalty (device double). */
+int svx_del_penalty(svx_ctx *ctx, const float *scores, int64_t n, double frac, double *del_penalty);
+
+/* dense_traceback(bp) -> alignments                                            dp_utils.py:146-174
+ * bp [s0+1][s1+1]; align [s0+s1][4] int32 rows (x_start, x_len, y_start, y_len) in document
+ * order; *count = number of rows, or -SVX_ERR_* on failure. */
+int svx_dense_traceback(svx_ctx *ctx, const int32_t *bp, int s0, int s1, int32_t *align, int32_t *count);
+
+/* sparse_traceback(csum, xp, yp, b_offset, xsize, ysize) -> (alignments, scores)  dp_utils.py:105-143
+ * (+ process_scores :89-102).  align [xsize+ysize][4], scores [xsize+ysize] float64, *count as above. */
+int svx_sparse_traceback(svx_ctx *ctx, const double *csum, const int32_t *xp, const int32_t *yp,
+                         const int32_t *b_offset_out, int a_out, int B, int xsize, int ysize, int32_t *align,
+                         double *scores, int32_t *count);
+
+/* upsample_alignment + extend_alignments + alignment_to_search_path  dp_utils.py:261-275,228-258,199-225
+ * align [*n_align][4] rows of the coarser level (upsample != 0; size0/size1 = finer sizes) or of
+ * the same level (upsample == 0, dp_utils.py:485-486).  path [size0+size1+4][2]; *path_len =
+ * number of points or -SVX_ERR_*. */
+int svx_search_path(svx_ctx *ctx, const int32_t *align, const int32_t *n_align, int upsample, int size0,
+                    int size1, int32_t *path, int32_t *path_len);
+
+/* ---- the whole of dp_utils.vecalign() for a batch of document pairs -------------------- */
+
+typedef struct svx_align_params {
+    int32_t dtype;            /* svx_dtype of vecs0/vecs1 */
+    int32_t d;                /* embedding dimension */
+    int32_t n_types;          /* final_alignment_types, in the order of vecalign.py:154-162 */
+    int32_t types[2 * SVX_MAX_TYPES];
+    int32_t width_over2;      /* dp_utils.py:391-393: values < 3 are raised to 3 */
+    int32_t max_size_full_dp; /* dp_utils.py:403-408 */
+    int32_t costs_sample_size;
+    int32_t num_samps_for_norm;
+    double del_percentile_frac;
+} svx_align_params;
+
+typedef struct svx_pair {
+    const void *vecs0, *vecs1; /* [k0][n][d], [k1][m][d] of params.dtype; NOT modified */
+    int32_t n, m, k0, k1;
+    /* Random row indices in the reference's draw order.  norm_idx: for each depth
+     * 0..L: [k1][S1] indices into side 1 (used for n0), then [k0][S0] into side 0 (used for n1),
+     * S1 = ceil(num_samps/k1), S0 = ceil(num_samps/k0); a side whose norms are overridden at depth 0
+     * contributes no indices at depth 0.  knob_idx: for each depth: x[c] then y[c], c =
+     * svx_knob_count(n_l, m_l, costs_sample_size) (full enumeration when n_l*m_l < sample size). */
+    const int32_t *norm_idx;
+    const int32_t *knob_idx;
+    const float *norms0, *norms1; /* optional depth-0 overrides [k0][n], [k1][m] (dp_utils.py:428-444) */
+    /* outputs */
+    int32_t *align;   /* [n+m+2][4] rows (x_start, x_len, y_start, y_len) */
+    double *scores;   /* [n+m+2] */
+    int32_t *info;    /* [2]: info[0] = number of alignments, info[1] = 0 or SVX_ERR_* */
+    double *del_pen;  /* optional [L+1]: deletion penalty per depth */
+} svx_pair;
+
+/* Number of halvings dp_utils.py:403-408 performs (max_depth). */
+int svx_num_levels(int n, int m, int max_size_full_dp);
+/* Length of each of the two knob index arrays at a level of sizes (n_l, m_l): dp_utils.py:286-302. */
+int64_t svx_knob_count(int n_l, int m_l, int costs_sample_size);
+
+/* vecalign(vecs0, vecs1, final_alignment_types, del_percentile_frac, width_over2,
+ *          max_size_full_dp, costs_sample_size, num_samps_for_norm, norms0, norms1) -> stack
+ *                                                                              dp_utils.py:381-537
+ * for n_pairs independent document pairs (pairs: HOST array).  Produces stack[0]
+ * ['final_alignments'] and ['alignment_scores'] per pair. */
+int svx_align_batch(svx_ctx *ctx, const svx_align_params *params, const svx_pair *pairs, int n_pairs);
+
+/* Device time of the named stage of the last svx_align_batch call, in milliseconds, measured with
+ * HIP events on the context's stream when profiling is on (svx_set_profiling); stage names:
+ * "pyramid", "knob", "dense", "path", "band_costs", "band_dp", "traceback", "total". -1 if unknown. */
+int svx_set_profiling(svx_ctx *ctx, int on);
+double svx_stage_ms(svx_ctx *ctx, const char *stage);
+/* Number of launches of the dominant kernel (band_costs) in the last batch, for roofline math. */
+int svx_stage_launches(svx_ctx *ctx, const char *stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVX_H */

@@ -1,0 +1,592 @@
+// svx_api.hip -- the C ABI (include/svx.h): context, scratch arena, per-op entry points and the
+// fused batch pipeline that restates dp_utils.vecalign() (svecalign/vecalign/dp_utils.py:381-537)
+// as a fixed sequence of batched kernel launches with no host round trip.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "svx_common.h"
+
+static char g_err[512] = "";
+
+int svx_fail(svx_ctx* ctx, int code, const char* fmt, ...) {
+    char* dst = ctx ? ctx->err : g_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static const char* kStageNames[] = {"pyr0",       "pyrN",     "pyr_aux",      "knob_scores",  "knob",      "dense_costs",
+                                    "dense_dp",   "path",     "band_costs0",  "band_costsN",  "band_dp0",  "band_dpN",
+                                    "traceback",  "setup",    "total"};
+enum {
+    S_PYR0 = 0, S_PYRN, S_PYR_AUX, S_KNOB_SCORES, S_KNOB, S_DENSE_COSTS, S_DENSE_DP, S_PATH, S_BAND_COSTS0, S_BAND_COSTSN,
+    S_BAND_DP0, S_BAND_DPN, S_TRACEBACK, S_SETUP, S_TOTAL, S_COUNT
+};
+
+struct StageRec {
+    int stage;
+    hipEvent_t a, b;
+};
+
+struct svx_ctx_ext : svx_ctx {
+    double ms[S_COUNT];
+    int launches[S_COUNT];
+    std::vector<StageRec> recs;
+    std::vector<SvxPairDev> host;  // descriptors of the last batch (kept alive for the async upload)
+};
+
+static inline svx_ctx_ext* X(svx_ctx* c) { return static_cast<svx_ctx_ext*>(c); }
+
+struct StageScope {
+    svx_ctx_ext* c;
+    StageRec r;
+    bool on;
+    StageScope(svx_ctx* ctx, int stage) : c(X(ctx)), on(ctx->profiling != 0) {
+        r.stage = stage;
+        if (on) {
+            (void)hipEventCreate(&r.a);
+            (void)hipEventCreate(&r.b);
+            (void)hipEventRecord(r.a, c->stream);
+        }
+    }
+    ~StageScope() {
+        if (on) {
+            (void)hipEventRecord(r.b, c->stream);
+            c->recs.push_back(r);
+        }
+        c->launches[r.stage]++;
+    }
+};
+
+extern "C" {
+
+const char* svx_version(void) { return "svx 0.1 (gfx950)"; }
+
+int svx_create(int device_id, svx_ctx** out) {
+    if (!out) return svx_fail(nullptr, SVX_ERR_ARG, "svx_create: out is NULL");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return svx_fail(nullptr, SVX_ERR_HIP, "svx_create: no HIP device (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev) return svx_fail(nullptr, SVX_ERR_ARG, "svx_create: device %d of %d", device_id, ndev);
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) return svx_fail(nullptr, SVX_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    svx_ctx_ext* c = new svx_ctx_ext();
+    c->device = device_id;
+    c->stream = nullptr;
+    c->arena = nullptr;
+    c->arena_bytes = 0;
+    c->arena_used = 0;
+    c->err[0] = 0;
+    c->profiling = 0;
+    for (int i = 0; i < S_COUNT; i++) { c->ms[i] = -1.0; c->launches[i] = 0; }
+    *out = c;
+    return SVX_OK;
+}
+
+int svx_destroy(svx_ctx* ctx) {
+    if (!ctx) return SVX_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    delete X(ctx);
+    return SVX_OK;
+}
+
+int svx_set_stream(svx_ctx* ctx, void* hip_stream) {
+    if (!ctx) return SVX_ERR_ARG;
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return SVX_OK;
+}
+
+int svx_synchronize(svx_ctx* ctx) {
+    if (!ctx) return SVX_ERR_ARG;
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SVX_OK;
+}
+
+const char* svx_last_error(const svx_ctx* ctx) { return ctx ? ctx->err : g_err; }
+
+int64_t svx_scratch_bytes(const svx_ctx* ctx) { return ctx ? (int64_t)ctx->arena_bytes : 0; }
+
+int svx_set_profiling(svx_ctx* ctx, int on) {
+    if (!ctx) return SVX_ERR_ARG;
+    ctx->profiling = on;
+    return SVX_OK;
+}
+
+static int stage_index(const char* name) {
+    for (int i = 0; i < S_COUNT; i++)
+        if (strcmp(name, kStageNames[i]) == 0) return i;
+    return -1;
+}
+
+double svx_stage_ms(svx_ctx* ctx, const char* stage) {
+    if (!ctx || !stage) return -1.0;
+    int i = stage_index(stage);
+    return i < 0 ? -1.0 : X(ctx)->ms[i];
+}
+
+int svx_stage_launches(svx_ctx* ctx, const char* stage) {
+    if (!ctx || !stage) return -1;
+    int i = stage_index(stage);
+    return i < 0 ? -1 : X(ctx)->launches[i];
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------ arena
+static int arena_reserve(svx_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->arena_bytes) return SVX_OK;
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->arena) SVX_HIP(ctx, hipFree(ctx->arena));
+    ctx->arena = nullptr;
+    ctx->arena_bytes = 0;
+    size_t want = bytes + bytes / 16 + (1 << 20);
+    hipError_t e = hipMalloc(&ctx->arena, want);
+    if (e != hipSuccess) return svx_fail(ctx, SVX_ERR_NOMEM, "scratch arena: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    ctx->arena_bytes = want;
+    return SVX_OK;
+}
+
+struct Bump;
+template <class T>
+static inline void set_off(T*& p, Bump& b, size_t bytes);
+
+struct Bump {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    }
+};
+
+template <class T>
+static inline void set_off(T*& p, Bump& b, size_t bytes) {
+    p = reinterpret_cast<T*>(b.take(bytes) + 1);
+}
+
+static int make_types(svx_ctx* ctx, const int32_t* types, int T, SvxTypes* out) {
+    if (T < 0 || T > SVX_MAX_TYPES) return svx_fail(ctx, SVX_ERR_ARG, "%d alignment types (max %d)", T, SVX_MAX_TYPES);
+    out->n = T;
+    out->maxstep = 1;
+    for (int t = 0; t < T; t++) {
+        int x = types[2 * t], y = types[2 * t + 1];
+        if (x < 1 || y < 1 || x > 100 || y > 100) return svx_fail(ctx, SVX_ERR_ARG, "alignment type (%d,%d): sizes must be >= 1", x, y);
+        out->x[t] = (int8_t)x;
+        out->y[t] = (int8_t)y;
+        if (x + y > out->maxstep) out->maxstep = x + y;
+    }
+    out->x[T] = 0; out->y[T] = 1;
+    out->x[T + 1] = 1; out->y[T + 1] = 0;
+    return SVX_OK;
+}
+
+static int check_dim(svx_ctx* ctx, int d) {
+    if (d <= 0 || d % 8 != 0 || d > SVX_MAX_DIM)
+        return svx_fail(ctx, SVX_ERR_ARG, "embedding dimension %d: must be a positive multiple of 8, at most %d", d, SVX_MAX_DIM);
+    return SVX_OK;
+}
+
+#define NEED(ctx, cond, ...) \
+    do { if (!(cond)) return svx_fail(ctx, SVX_ERR_ARG, __VA_ARGS__); } while (0)
+
+extern "C" {
+
+// ------------------------------------------------------------------------------ per-op entry points
+int svx_dense_costs(svx_ctx* ctx, const float* vecs0, int k0, int s0, const float* vecs1, int k1, int s1, int d,
+                    const float* norm0, const float* norm1, int offset0, int offset1, float* costs) {
+    NEED(ctx, ctx && vecs0 && vecs1 && norm0 && norm1 && costs, "svx_dense_costs: null argument");
+    NEED(ctx, k0 > offset0 && k1 > offset1 && offset0 >= 0 && offset1 >= 0, "svx_dense_costs: offsets (%d,%d) outside %d/%d layers", offset0, offset1, k0, k1);
+    int rc = check_dim(ctx, d);
+    if (rc) return rc;
+    return svxl_dense_costs(ctx, vecs0 + (size_t)offset0 * s0 * d, s0, vecs1 + (size_t)offset1 * s1 * d, s1, d,
+                            norm0 + (size_t)offset0 * s0, norm1 + (size_t)offset1 * s1, offset0 + 1, offset1 + 1, costs);
+}
+
+int svx_dense_dp(svx_ctx* ctx, const float* cost, int s0, int s1, float pen, double* csum, int32_t* bp) {
+    NEED(ctx, ctx && bp && (cost || s0 == 0 || s1 == 0), "svx_dense_dp: null argument");
+    NEED(ctx, s0 >= 0 && s1 >= 0, "svx_dense_dp: negative size");
+    return svxl_dense_dp(ctx, cost, s0, s1, pen, csum, bp);
+}
+
+int svx_score_path(svx_ctx* ctx, const int32_t* xx, const int32_t* yy, int64_t n, const float* norm1, const float* norm2,
+                   const float* vecs1, int rows1, const float* vecs2, int rows2, int d, float* out) {
+    NEED(ctx, ctx && xx && yy && norm1 && norm2 && vecs1 && vecs2 && out, "svx_score_path: null argument");
+    NEED(ctx, rows1 > 0 && rows2 > 0, "svx_score_path: empty vecs");
+    int rc = check_dim(ctx, d);
+    if (rc) return rc;
+    return svxl_score_path(ctx, xx, yy, n, norm1, norm2, vecs1, rows1, vecs2, rows2, d, out);
+}
+
+int svx_sparse_costs(svx_ctx* ctx, const float* vecs0, int k0, int xsize, const float* vecs1, int k1, int ysize, int d,
+                     const float* norms0, const float* norms1, const int32_t* path, int A, const int32_t* types_host, int T,
+                     int width_over2, float* costs, int32_t* b_offset) {
+    NEED(ctx, ctx && vecs0 && vecs1 && norms0 && norms1 && path && b_offset && (costs || T == 0), "svx_sparse_costs: null argument");
+    NEED(ctx, width_over2 >= 1 && A >= 0, "svx_sparse_costs: bad width/path length");
+    int rc = check_dim(ctx, d);
+    if (rc) return rc;
+    SvxTypes ty;
+    rc = make_types(ctx, types_host, T, &ty);
+    if (rc) return rc;
+    int mx = 0, my = 0;
+    for (int t = 0; t < T; t++) { if (ty.x[t] > mx) mx = ty.x[t]; if (ty.y[t] > my) my = ty.y[t]; }
+    if (mx > k0) return svx_fail(ctx, SVX_ERR_OVERLAPS, "%d x overlaps requrested (via alignment_types), but vecs0 only has %d", mx, k0);
+    if (my > k1) return svx_fail(ctx, SVX_ERR_OVERLAPS, "%d y overlaps requrested (via alignment_types), but vecs1 only has %d", my, k1);
+    rc = arena_reserve(ctx, 256);
+    if (rc) return rc;
+    int* status = reinterpret_cast<int*>(ctx->arena);
+    SVX_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int), ctx->stream));
+    rc = svxl_band_costs(ctx, vecs0, k0, xsize, vecs1, k1, ysize, d, SVX_F32, nullptr, nullptr, norms0, norms1, path, A, ty,
+                         width_over2, costs, b_offset, status);
+    if (rc) return rc;
+    int hs = 0;
+    SVX_HIP(ctx, hipMemcpyAsync(&hs, status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (hs != 0) return svx_fail(ctx, hs, "search path is not a unit-step lattice path starting at (0,0)");
+    return SVX_OK;
+}
+
+int svx_sparse_dp(svx_ctx* ctx, const float* costs, const int32_t* b_offset_in, int A, int B, const int32_t* types_host,
+                  int T, double del_penalty, int x_in_size, int y_in_size, double* csum, int32_t* xp, int32_t* yp,
+                  int32_t* b_offset_out) {
+    NEED(ctx, ctx && b_offset_in && csum && xp && yp && b_offset_out && (costs || T == 0), "svx_sparse_dp: null argument");
+    NEED(ctx, A >= 1 && B >= 1, "svx_sparse_dp: empty cost band");
+    SvxTypes ty;
+    int rc = make_types(ctx, types_host, T, &ty);
+    if (rc) return rc;
+    return svxl_sparse_dp(ctx, costs, b_offset_in, A, B, ty, del_penalty, x_in_size, y_in_size, csum, xp, yp, b_offset_out);
+}
+
+int svx_make_norm1(svx_ctx* ctx, float* vecs, int64_t rows, int d) {
+    NEED(ctx, ctx && (vecs || rows == 0), "svx_make_norm1: null argument");
+    int rc = check_dim(ctx, d);
+    if (rc) return rc;
+    return svxl_make_norm1(ctx, vecs, rows, d);
+}
+
+int svx_downsample(svx_ctx* ctx, const float* vecs, int k, int n, int d, float* half) {
+    NEED(ctx, ctx && vecs && (half || n < 2), "svx_downsample: null argument");
+    int rc = check_dim(ctx, d);
+    if (rc) return rc;
+    const int h = n / 2;
+    if (h <= 0 || k <= 0) return SVX_OK;
+    const int nblk = (h + SVX_PYR_SLOTS - 1) / SVX_PYR_SLOTS;
+    Bump b;
+    size_t o_part = b.take((size_t)k * nblk * d * sizeof(float));
+    size_t o_mean = b.take((size_t)k * d * sizeof(float));
+    rc = arena_reserve(ctx, b.off);
+    if (rc) return rc;
+    float* part = reinterpret_cast<float*>(ctx->arena + o_part);
+    float* mean = reinterpret_cast<float*>(ctx->arena + o_mean);
+    if ((rc = svxl_pairsum(ctx, vecs, k, n, d, half, part, nblk))) return rc;
+    if ((rc = svxl_colmean_plain(ctx, part, k, nblk, d, h, mean))) return rc;
+    return svxl_sub_mean(ctx, half, k, h, d, mean);
+}
+
+int svx_compute_norms(svx_ctx* ctx, const float* vecs0, int k0, int n0, const float* vecs1, int k1, int n1, int d,
+                      const int32_t* idx, int samples_per_overlap, float* norms0) {
+    NEED(ctx, ctx && vecs0 && vecs1 && idx && norms0, "svx_compute_norms: null argument");
+    NEED(ctx, n1 > 0 && samples_per_overlap > 0 && k1 > 0, "svx_compute_norms: nothing to sample");
+    int rc = check_dim(ctx, d);
+    if (rc) return rc;
+    rc = arena_reserve(ctx, (size_t)d * sizeof(float) + 256);
+    if (rc) return rc;
+    float* rbar = reinterpret_cast<float*>(ctx->arena);
+    if ((rc = svxl_sample_mean_plain(ctx, vecs1, k1, n1, d, idx, samples_per_overlap, rbar))) return rc;
+    return svxl_norms_from_rbar(ctx, vecs0, (int64_t)k0 * n0, d, rbar, norms0);
+}
+
+int svx_del_penalty(svx_ctx* ctx, const float* scores, int64_t n, double frac, double* del_penalty) {
+    NEED(ctx, ctx && scores && del_penalty && n > 0, "svx_del_penalty: null/empty argument");
+    return svxl_del_penalty(ctx, scores, n, frac, del_penalty);
+}
+
+int svx_dense_traceback(svx_ctx* ctx, const int32_t* bp, int s0, int s1, int32_t* align, int32_t* count) {
+    NEED(ctx, ctx && bp && align && count, "svx_dense_traceback: null argument");
+    return svxl_dense_traceback(ctx, bp, s0, s1, align, count);
+}
+
+int svx_sparse_traceback(svx_ctx* ctx, const double* csum, const int32_t* xp, const int32_t* yp, const int32_t* b_offset_out,
+                         int a_out, int B, int xsize, int ysize, int32_t* align, double* scores, int32_t* count) {
+    NEED(ctx, ctx && csum && xp && yp && b_offset_out && align && scores && count, "svx_sparse_traceback: null argument");
+    return svxl_sparse_traceback(ctx, csum, xp, yp, b_offset_out, a_out, B, xsize, ysize, align, scores, count);
+}
+
+int svx_search_path(svx_ctx* ctx, const int32_t* align, const int32_t* n_align, int upsample, int size0, int size1,
+                    int32_t* path, int32_t* path_len) {
+    NEED(ctx, ctx && align && n_align && path && path_len, "svx_search_path: null argument");
+    return svxl_search_path(ctx, align, n_align, upsample, size0, size1, path, size0 + size1 + 4, path_len);
+}
+
+int svx_num_levels(int n, int m, int max_size_full_dp) {
+    long long s0 = n, s1 = m, lim = (long long)max_size_full_dp * max_size_full_dp;
+    int depth = 0;
+    while (s0 * s1 > lim) {
+        depth++;
+        s0 /= 2;
+        s1 /= 2;
+    }
+    return depth;
+}
+
+int64_t svx_knob_count(int n_l, int m_l, int costs_sample_size) {
+    long long p = (long long)n_l * m_l;
+    return p < costs_sample_size ? p : costs_sample_size;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------ fused batch
+__global__ void k_init_batch(const SvxPairDev* pairs) {
+    const SvxPairDev& P = pairs[blockIdx.x];
+    if (threadIdx.x != 0) return;
+    *P.status = 0;
+    for (int l = 0; l <= P.L; l++) {
+        if (P.lev[l].n_align) *P.lev[l].n_align = 0;
+        if (P.lev[l].path_len) *P.lev[l].path_len = 0;
+    }
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const svx_pair* pairs, int n_pairs) {
+    NEED(ctx, ctx && prm && (pairs || n_pairs == 0), "svx_align_batch: null argument");
+    if (n_pairs <= 0) return SVX_OK;
+    svx_ctx_ext* cx = X(ctx);
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = check_dim(ctx, prm->d);
+    if (rc) return rc;
+    const int d = prm->d, dtype = prm->dtype;
+    NEED(ctx, dtype == SVX_F32 || dtype == SVX_F16 || dtype == SVX_BF16, "svx_align_batch: unknown dtype %d", dtype);
+    NEED(ctx, prm->max_size_full_dp >= 1, "svx_align_batch: max_size_full_dp must be >= 1");
+    NEED(ctx, prm->costs_sample_size >= 1, "svx_align_batch: costs_sample_size must be >= 1");
+    NEED(ctx, prm->num_samps_for_norm >= 0, "svx_align_batch: num_samps_for_norm must be >= 0");
+    SvxTypes tfinal, t11;
+    if ((rc = make_types(ctx, prm->types, prm->n_types, &tfinal))) return rc;
+    const int32_t one_one[2] = {1, 1};
+    make_types(ctx, one_one, 1, &t11);
+    int W = prm->width_over2 < 3 ? 3 : prm->width_over2;  // dp_utils.py:391-393
+    const int B = 2 * W;
+    int mx = 0, my = 0;
+    for (int t = 0; t < tfinal.n; t++) { if (tfinal.x[t] > mx) mx = tfinal.x[t]; if (tfinal.y[t] > my) my = tfinal.y[t]; }
+    const size_t esz = dtype == SVX_F32 ? 4 : 2;
+    (void)esz;
+
+    // ---- plan: level sizes, scratch layout, launch extents
+    std::vector<SvxPairDev>& host = cx->host;
+    host.assign(n_pairs, SvxPairDev());
+    Bump bump;
+    const size_t o_desc = bump.take((size_t)n_pairs * sizeof(SvxPairDev));
+    int maxL = 0, max_ksum = 0, max_kn = 0, max_ds0 = 0, max_ds1 = 0;
+    int max_nblk[SVX_MAX_LEVELS] = {0}, max_A[SVX_MAX_LEVELS] = {0};
+    bool any_L0 = false;
+#define OFF(ptr_field, bytes) set_off(ptr_field, bump, bytes)
+    // offsets are stored +1 so that a null pointer stays distinguishable; patched below
+    for (int p = 0; p < n_pairs; p++) {
+        const svx_pair& in = pairs[p];
+        SvxPairDev& P = host[p];
+        memset(&P, 0, sizeof(P));
+        NEED(ctx, in.vecs0 && in.vecs1 && in.align && in.scores && in.info && in.knob_idx, "pair %d: null pointer", p);
+        NEED(ctx, in.n >= 1 && in.m >= 1 && in.k0 >= 1 && in.k1 >= 1, "pair %d: empty document or no overlap layers", p);
+        if (mx > in.k0) return svx_fail(ctx, SVX_ERR_OVERLAPS, "%d x overlaps requrested (via alignment_types), but vecs0 only has %d", mx, in.k0);
+        if (my > in.k1) return svx_fail(ctx, SVX_ERR_OVERLAPS, "%d y overlaps requrested (via alignment_types), but vecs1 only has %d", my, in.k1);
+        const int L = svx_num_levels(in.n, in.m, prm->max_size_full_dp);
+        NEED(ctx, L < SVX_MAX_LEVELS, "pair %d: %d pyramid levels (max %d)", p, L + 1, SVX_MAX_LEVELS);
+        P.v[0] = in.vecs0; P.v[1] = in.vecs1;
+        P.K[0] = in.k0; P.K[1] = in.k1;
+        P.L = L; P.d = d;
+        P.norm_override[0] = in.norms0 != nullptr;
+        P.norm_override[1] = in.norms1 != nullptr;
+        P.status = in.info + 1;
+        if (L > maxL) maxL = L;
+        if (L == 0) any_L0 = true;
+        if (in.k0 + in.k1 > max_ksum) max_ksum = in.k0 + in.k1;
+        const int S_from[2] = {in.k0 > 0 ? ceil_div(prm->num_samps_for_norm, in.k0) : 0,
+                               in.k1 > 0 ? ceil_div(prm->num_samps_for_norm, in.k1) : 0};
+        const int32_t* nidx = in.norm_idx;
+        const int32_t* kidx = in.knob_idx;
+        for (int l = 0; l <= L; l++) {
+            SvxLevel& Lv = P.lev[l];
+            const int K[2] = {in.k0, in.k1};
+            for (int s = 0; s < 2; s++) {
+                Lv.n[s] = (s == 0 ? in.n : in.m) >> l;
+                Lv.nblk[s] = ceil_div((Lv.n[s] + 1) / 2, SVX_PYR_SLOTS);
+                if (Lv.nblk[s] > max_nblk[l]) max_nblk[l] = Lv.nblk[s];
+            }
+            // sampled indices in the reference's draw order: into side 1 (for n0), then into side 0 (for n1)
+            for (int s = 1; s >= 0; s--) {
+                const bool skip = (l == 0) && P.norm_override[1 - s];  // the side whose norms use these samples
+                Lv.S[s] = skip ? 0 : S_from[s];
+                Lv.sidx[s] = nullptr;
+                if (Lv.S[s] > 0) {
+                    NEED(ctx, nidx != nullptr, "pair %d: norm_idx is NULL", p);
+                    Lv.sidx[s] = nidx;
+                    nidx += (size_t)K[s] * Lv.S[s];
+                }
+            }
+            for (int s = 0; s < 2; s++) {
+                if (l >= 1) {
+                    Lv.npart[s] = P.lev[l - 1].nblk[s];
+                    OFF(Lv.P[s], (size_t)K[s] * Lv.n[s] * d * sizeof(float));
+                    OFF(Lv.part[s], (size_t)K[s] * Lv.npart[s] * d * sizeof(float));
+                    OFF(Lv.mean[s], (size_t)K[s] * d * sizeof(float));
+                } else {
+                    OFF(Lv.inv[s], (size_t)K[s] * Lv.n[s] * sizeof(float));
+                }
+                OFF(Lv.rbar[s], (size_t)d * sizeof(float));
+                if (l == 0 && P.norm_override[s]) Lv.nrm[s] = const_cast<float*>(s == 0 ? in.norms0 : in.norms1);
+                else OFF(Lv.nrm[s], (size_t)K[s] * Lv.n[s] * sizeof(float));
+            }
+            const int64_t kn = svx_knob_count(Lv.n[0], Lv.n[1], prm->costs_sample_size);
+            Lv.kn = (int)kn;
+            Lv.kx = kidx;
+            Lv.ky = kidx + kn;
+            kidx += 2 * kn;
+            if (Lv.kn > max_kn) max_kn = Lv.kn;
+            OFF(Lv.kscore, (size_t)kn * sizeof(float));
+            if (in.del_pen) Lv.pen = in.del_pen + l;
+            else OFF(Lv.pen, sizeof(double));
+            const bool refined = (l < L) || (L == 0);
+            const int rows_cap = Lv.n[0] + Lv.n[1] + 2;
+            if (refined) {
+                const int cap = Lv.n[0] + Lv.n[1] + 4;
+                const int T = (l == 0) ? tfinal.n : 1;
+                Lv.path_cap = cap;
+                if (cap > max_A[l]) max_A[l] = cap;
+                OFF(Lv.path, (size_t)cap * 2 * sizeof(int));
+                OFF(Lv.path_len, sizeof(int));
+                OFF(Lv.costs, (size_t)(T > 0 ? T : 1) * cap * B * sizeof(float));
+                OFF(Lv.boff, (size_t)cap * sizeof(int));
+                OFF(Lv.csum, (size_t)(cap + 2) * B * sizeof(double));
+                OFF(Lv.xp, (size_t)(cap + 2) * B * sizeof(int));
+                OFF(Lv.yp, (size_t)(cap + 2) * B * sizeof(int));
+                OFF(Lv.boff_out, (size_t)(cap + 2) * sizeof(int));
+            }
+            if (l == 0) {
+                Lv.align = in.align;
+                Lv.scores = in.scores;
+                Lv.n_align = in.info;
+            } else {
+                OFF(Lv.align, (size_t)rows_cap * 4 * sizeof(int));
+                OFF(Lv.scores, (size_t)rows_cap * sizeof(double));
+                OFF(Lv.n_align, sizeof(int));
+            }
+        }
+        const SvxLevel& top = P.lev[L];
+        if (top.n[0] > max_ds0) max_ds0 = top.n[0];
+        if (top.n[1] > max_ds1) max_ds1 = top.n[1];
+        OFF(P.dcost, (size_t)top.n[0] * top.n[1] * sizeof(float));
+        OFF(P.dbp, (size_t)(top.n[0] + 1) * (top.n[1] + 1) * sizeof(int));
+    }
+#undef OFF
+    if ((rc = arena_reserve(ctx, bump.off))) return rc;
+    // patch offsets (+1) into device pointers
+    char* base = ctx->arena;
+    const char* ulo = reinterpret_cast<const char*>(1);
+    const char* uhi = reinterpret_cast<const char*>(bump.off + 1);
+    auto patch = [&](auto& ptr) {
+        const char* v = reinterpret_cast<const char*>(ptr);
+        if (v >= ulo && v < uhi) ptr = reinterpret_cast<typename std::remove_reference<decltype(ptr)>::type>(base + (v - ulo));
+    };
+    for (int p = 0; p < n_pairs; p++) {
+        SvxPairDev& P = host[p];
+        const svx_pair& in = pairs[p];
+        for (int l = 0; l <= P.L; l++) {
+            SvxLevel& Lv = P.lev[l];
+            for (int s = 0; s < 2; s++) {
+                patch(Lv.P[s]); patch(Lv.part[s]); patch(Lv.mean[s]); patch(Lv.rbar[s]); patch(Lv.inv[s]);
+                if (!(l == 0 && P.norm_override[s])) patch(Lv.nrm[s]);
+            }
+            patch(Lv.kscore);
+            if (!in.del_pen) patch(Lv.pen);
+            patch(Lv.path); patch(Lv.path_len); patch(Lv.costs); patch(Lv.boff); patch(Lv.csum); patch(Lv.xp); patch(Lv.yp);
+            patch(Lv.boff_out);
+            if (l > 0) { patch(Lv.align); patch(Lv.scores); patch(Lv.n_align); }
+        }
+        patch(P.dcost);
+        patch(P.dbp);
+    }
+    SvxPairDev* dpairs = reinterpret_cast<SvxPairDev*>(base + o_desc);
+    hipStream_t st = ctx->stream;
+
+    // ---- run
+    for (int i = 0; i < S_COUNT; i++) { cx->ms[i] = 0.0; cx->launches[i] = 0; }
+    for (auto& r : cx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    cx->recs.clear();
+    {
+        StageScope total(ctx, S_TOTAL);
+        {
+            StageScope sc(ctx, S_SETUP);
+            SVX_HIP(ctx, hipMemcpyAsync(dpairs, host.data(), (size_t)n_pairs * sizeof(SvxPairDev), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_init_batch, dim3(n_pairs), dim3(64), 0, st, dpairs);
+            SVX_LAUNCH_CHECK(ctx, "k_init_batch");
+            if (prm->num_samps_for_norm == 0) {
+                // compute_norms returns ones without samples (dp_utils.py:356-357): rbar = 0 -> 1 - 0
+                for (int p = 0; p < n_pairs; p++)
+                    for (int l = 0; l <= host[p].L; l++)
+                        for (int s = 0; s < 2; s++)
+                            SVX_HIP(ctx, hipMemsetAsync(host[p].lev[l].rbar[s], 0, (size_t)d * sizeof(float), st));
+            }
+        }
+        for (int l = 0; l <= maxL; l++) {
+            // pyramid: the streaming pass of level l (S_PYR0 / S_PYRN) and its small helpers
+            StageScope sc(ctx, l == 0 ? S_PYR0 : S_PYRN);
+            if ((rc = svxl_pyramid_level(ctx, dpairs, n_pairs, l, dtype, d, max_nblk[l], max_ksum, 0))) return rc;
+        }
+        {
+            StageScope sc(ctx, S_KNOB_SCORES);
+            if ((rc = svxl_knob_scores(ctx, dpairs, n_pairs, maxL, max_kn, dtype, d))) return rc;
+        }
+        {
+            StageScope sc(ctx, S_KNOB);
+            if ((rc = svxl_del_penalty_batch(ctx, dpairs, n_pairs, maxL + 1, prm->del_percentile_frac))) return rc;
+        }
+        {
+            StageScope sc(ctx, S_DENSE_COSTS);
+            if ((rc = svxl_dense_costs_batch(ctx, dpairs, n_pairs, max_ds0, max_ds1, dtype, d))) return rc;
+        }
+        {
+            StageScope sc(ctx, S_DENSE_DP);
+            if ((rc = svxl_dense_stage_batch(ctx, dpairs, n_pairs, max_ds0))) return rc;
+        }
+        (void)any_L0;
+        const int first_depth = maxL > 0 ? maxL - 1 : 0;
+        for (int depth = first_depth; depth >= 0; depth--) {
+            const SvxTypes& ty = depth == 0 ? tfinal : t11;
+            {
+                StageScope sc(ctx, S_PATH);
+                if ((rc = svxl_search_path_batch(ctx, dpairs, n_pairs, depth))) return rc;
+            }
+            {
+                StageScope sc(ctx, depth == 0 ? S_BAND_COSTS0 : S_BAND_COSTSN);
+                if ((rc = svxl_band_costs_batch(ctx, dpairs, n_pairs, depth, max_A[depth], ty, W, dtype, d))) return rc;
+            }
+            {
+                StageScope sc(ctx, depth == 0 ? S_BAND_DP0 : S_BAND_DPN);
+                if ((rc = svxl_sparse_dp_batch(ctx, dpairs, n_pairs, depth, ty, B))) return rc;
+            }
+            {
+                StageScope sc(ctx, S_TRACEBACK);
+                if ((rc = svxl_sparse_traceback_batch(ctx, dpairs, n_pairs, depth, B))) return rc;
+            }
+        }
+    }
+    if (ctx->profiling) {
+        SVX_HIP(ctx, hipStreamSynchronize(st));
+        for (auto& r : cx->recs) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) cx->ms[r.stage] += ms;
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+        }
+        cx->recs.clear();
+    }
+    return SVX_OK;
+}

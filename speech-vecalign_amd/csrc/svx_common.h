@@ -1,0 +1,187 @@
+// svx_common.h -- internal declarations shared by the libsvx translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/svx.h"
+
+#define SVX_WAVE 64
+
+// Row-pair slots handled by one k_pyramid workgroup (4 waves x 8 slots).
+#define SVX_PYR_SLOTS 32
+// Band-cost tiling: path points per chunk, band cells per chunk, rows staged per side.
+#define SVX_BC_TA 32
+#define SVX_BC_TB 16
+#define SVX_BC_ROWS 48
+
+// ---- element types ---------------------------------------------------------------------
+struct ElemF32 {
+    using storage = float;
+    static constexpr int VEC = 4;  // elements per 16-byte piece
+    static constexpr int DT = SVX_F32;
+};
+struct ElemF16 {
+    using storage = uint16_t;
+    static constexpr int VEC = 8;
+    static constexpr int DT = SVX_F16;
+};
+struct ElemBF16 {
+    using storage = uint16_t;
+    static constexpr int VEC = 8;
+    static constexpr int DT = SVX_BF16;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ float f16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+
+// Load one 16-byte piece and widen to VEC floats.
+template <typename E>
+__device__ __forceinline__ void load_piece(const typename E::storage* p, float* out);
+template <>
+__device__ __forceinline__ void load_piece<ElemF32>(const float* p, float* out) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void load_piece<ElemF16>(const uint16_t* p, float* out) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        out[2 * i] = f16_to_f32((uint16_t)(w[i] & 0xffffu));
+        out[2 * i + 1] = f16_to_f32((uint16_t)(w[i] >> 16));
+    }
+}
+template <>
+__device__ __forceinline__ void load_piece<ElemBF16>(const uint16_t* p, float* out) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        out[2 * i] = __uint_as_float(w[i] << 16);
+        out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 1; m < SVX_WAVE; m <<= 1) v += __shfl_xor(v, m, SVX_WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 1; m < SVX_WAVE; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, SVX_WAVE));
+    return v;
+}
+
+// ---- per-pair device descriptors of the fused pipeline (svx_align_batch) ---------------
+struct SvxLevel {
+    int n[2];          // rows per side at this level
+    int nblk[2];       // k_pyramid workgroups along the rows of this level
+    int npart[2];      // column-sum partials feeding THIS level's mean (= nblk of level-1)
+    int S[2];          // sampled rows per layer taken FROM side s
+    float* P[2];       // level >= 1: [K][n][d] pair sums of level-1; layer 0 becomes the normalised rows
+    float* part[2];    // level >= 1: [K][npart][d]
+    float* mean[2];    // level >= 1: [K][d]
+    float* rbar[2];    // [d] mean of the sampled normalised rows of side s
+    float* inv[2];     // level 0: [K][n] 1/(||row|| + 1e-5)
+    float* nrm[2];     // [K][n] the reference's n0 / n1
+    const int* sidx[2];  // [K_s][S_s] sampled row indices into side s
+    const int* kx;     // knob sample indices (side 0 / side 1 rows)
+    const int* ky;
+    int kn;
+    int path_cap;
+    float* kscore;     // [kn]
+    double* pen;       // deletion penalty of this level
+    int* path;         // [path_cap][2]
+    int* path_len;
+    float* costs;      // [T][A][B]
+    int* boff;         // [A]
+    double* csum;      // [A+2][B]
+    int* xp;
+    int* yp;
+    int* boff_out;     // [A+2]
+    int* align;        // [n0+n1+2][4]
+    int* n_align;
+    double* scores;
+};
+
+struct SvxPairDev {
+    const void* v[2];
+    int K[2];
+    int L;             // max_depth
+    int d;
+    int norm_override[2];
+    float* dcost;      // dense stage at level L: [s0][s1]
+    int* dbp;          // [s0+1][s1+1]
+    int* status;       // info[1]
+    SvxLevel lev[SVX_MAX_LEVELS];
+};
+
+struct SvxTypes {
+    int n;
+    int maxstep;               // max(x+y) over types and the two deletions
+    int8_t x[SVX_MAX_TYPES + 2];  // types..., then (0,1), (1,0)
+    int8_t y[SVX_MAX_TYPES + 2];
+};
+
+// ---- host-side context -----------------------------------------------------------------
+struct svx_ctx {
+    int device;
+    hipStream_t stream;
+    char* arena;
+    size_t arena_bytes;
+    size_t arena_used;
+    char err[512];
+    int profiling;
+};
+
+int svx_fail(svx_ctx* ctx, int code, const char* fmt, ...);
+#define SVX_HIP(ctx, call)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) return svx_fail(ctx, SVX_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+#define SVX_LAUNCH_CHECK(ctx, name)                                                            \
+    do {                                                                                       \
+        hipError_t e_ = hipGetLastError();                                                     \
+        if (e_ != hipSuccess) return svx_fail(ctx, SVX_ERR_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- kernel launchers (defined in the .hip files) ---------------------------------------
+// rows / pyramid (svx_rows.hip)
+int svxl_make_norm1(svx_ctx*, float* vecs, int64_t rows, int d);
+int svxl_pairsum(svx_ctx*, const float* vecs, int k, int n, int d, float* half, float* part, int nblk);
+int svxl_colmean_plain(svx_ctx*, const float* part, int k, int nblk, int d, int count, float* mean);
+int svxl_sub_mean(svx_ctx*, float* half, int k, int h, int d, const float* mean);
+int svxl_sample_mean_plain(svx_ctx*, const float* vecs, int k, int n, int d, const int* idx, int S, float* rbar);
+int svxl_norms_from_rbar(svx_ctx*, const float* vecs, int64_t rows, int d, const float* rbar, float* norms);
+int svxl_pyramid_level(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int level, int dtype, int d, int max_nblk,
+                       int max_ksum, int max_npart);
+// costs (svx_costs.hip)
+int svxl_score_path(svx_ctx*, const int* xx, const int* yy, int64_t n, const float* n1, const float* n2,
+                    const float* v1, int rows1, const float* v2, int rows2, int d, float* out);
+int svxl_knob_scores(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_levels, int max_kn, int dtype, int d);
+int svxl_dense_costs(svx_ctx*, const float* v0, int s0, const float* v1, int s1, int d, const float* n0,
+                     const float* n1, int mul0, int mul1, float* costs);
+int svxl_dense_costs_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_s0, int max_s1, int dtype, int d);
+int svxl_band_costs(svx_ctx*, const void* v0, int k0, int n, const void* v1, int k1, int m, int d, int dtype,
+                    const float* inv0, const float* inv1, const float* nrm0, const float* nrm1, const int* path,
+                    int A, const SvxTypes& types, int W, float* costs, int* boff, int* status);
+int svxl_band_costs_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int max_A, const SvxTypes& types,
+                          int W, int dtype, int d);
+// dp (svx_dp.hip)
+int svxl_dense_dp(svx_ctx*, const float* cost, int s0, int s1, float pen, double* csum, int* bp);
+int svxl_dense_stage_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_s0);
+int svxl_dense_traceback(svx_ctx*, const int* bp, int s0, int s1, int* align, int* count);
+int svxl_sparse_dp(svx_ctx*, const float* costs, const int* boff_in, int A, int B, const SvxTypes& types, double pen,
+                   int xs, int ys, double* csum, int* xp, int* yp, int* boff_out);
+int svxl_sparse_dp_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, const SvxTypes& types, int B);
+int svxl_sparse_traceback(svx_ctx*, const double* csum, const int* xp, const int* yp, const int* boff, int a_out,
+                          int B, int xs, int ys, int* align, double* scores, int* count);
+int svxl_sparse_traceback_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int B);
+int svxl_search_path(svx_ctx*, const int* align, const int* n_align, int upsample, int size0, int size1, int* path,
+                     int cap, int* path_len);
+int svxl_search_path_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth);
+int svxl_del_penalty(svx_ctx*, const float* scores, int64_t n, double frac, double* out);
+int svxl_del_penalty_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_levels, double frac);

@@ -1,0 +1,609 @@
+// svx_costs.hip -- similarity / cost kernels (MFMA): coarse dense costs, band ("sparse") costs
+// along the search path, and the sampled path scores that feed the deletion-penalty estimate.
+//
+// Reference semantics (paths relative to the reference repository):
+//   make_dense_costs   svecalign/vecalign/dp_core.pyx:36-77
+//   score_path         svecalign/vecalign/dp_core.pyx:143-161
+//   make_sparse_costs  svecalign/vecalign/dp_core.pyx:165-267
+//
+// Design.  A cost is 2pq(1 - <u,v>)/(1e-6 + n0 + n1) with u,v unit rows.  The rows stay in their
+// storage type (bf16 / fp16 / fp32, exactly representable products, fp32 accumulate in the matrix
+// cores) and the unit-normalisation is applied as the two scalars 1/(||u||+1e-5), 1/(||v||+1e-5)
+// in the epilogue, so normalised copies of level 0 are never written to HBM.
+//
+// Band kernel: one workgroup owns SVX_BC_TA consecutive path points x SVX_BC_TB band cells.  The
+// cells of that chunk only touch <= 47 consecutive rows per side, so the workgroup stages those
+// rows (all overlap layers) through LDS in 128-byte k-slabs and evaluates every needed
+// (type, x-row, y-row) product as 16x16 MFMA tiles; the epilogue picks the band cells out of the
+// accumulators, applies the cost formula in double like the reference, stages the [type][a][b]
+// block in LDS and writes it out coalesced.
+#include "svx_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int RS = 144;        // LDS row stride in bytes: 128-byte k-slab + 16 pad (conflict-free b128 reads)
+constexpr int SLAB_BYTES = 128;
+
+template <typename E>
+struct Mma;
+// Mma<E>: KS = elements per 128-byte slab, NK = k-steps per slab, frag = one lane's operand of one
+// k-step.  `lane_off(lane)` is the lane's byte offset inside a tile (row lane&15, k-group lane>>4).
+template <>
+struct Mma<ElemBF16> {
+    static constexpr int KS = 64, NK = 2, KSTEP_BYTES = 64;
+    using frag = uint4;
+    __device__ static __forceinline__ int lane_off(int lane) { return (lane & 15) * RS + 16 * (lane >> 4); }
+    __device__ static __forceinline__ frag load(const char* p) { return *reinterpret_cast<const uint4*>(p); }
+    __device__ static __forceinline__ void mma(f32x4_t& acc, const frag& a, const frag& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <>
+struct Mma<ElemF16> {
+    static constexpr int KS = 64, NK = 2, KSTEP_BYTES = 64;
+    using frag = uint4;
+    __device__ static __forceinline__ int lane_off(int lane) { return (lane & 15) * RS + 16 * (lane >> 4); }
+    __device__ static __forceinline__ frag load(const char* p) { return *reinterpret_cast<const uint4*>(p); }
+    __device__ static __forceinline__ void mma(f32x4_t& acc, const frag& a, const frag& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <>
+struct Mma<ElemF32> {
+    static constexpr int KS = 32, NK = 8, KSTEP_BYTES = 16;
+    using frag = float;
+    __device__ static __forceinline__ int lane_off(int lane) { return (lane & 15) * RS + 4 * (lane >> 4); }
+    __device__ static __forceinline__ frag load(const char* p) { return *reinterpret_cast<const float*>(p); }
+    __device__ static __forceinline__ void mma(f32x4_t& acc, const frag& a, const frag& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+};
+
+// Stage one 128-byte k-slab of `nrows` rows into LDS.  rowptr[r] = byte pointer to the row start
+// in global memory or nullptr for an all-zero row.
+template <typename E>
+__device__ __forceinline__ void stage_slab(char* slab, const char* const* rowptr, int nrows, int k0, int d, int tid,
+                                           int nthreads) {
+    using S = typename E::storage;
+    const int npieces = nrows * 8;
+    for (int q = tid; q < npieces; q += nthreads) {
+        const int r = q >> 3, p = q & 7;
+        const char* ptr = rowptr[r];
+        const int kel = k0 + p * E::VEC;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ptr != nullptr && kel < d) v = *reinterpret_cast<const uint4*>(ptr + (size_t)kel * sizeof(S));
+        *reinterpret_cast<uint4*>(slab + r * RS + p * 16) = v;
+    }
+}
+
+__device__ __forceinline__ float cost_formula(float sumx, int p, int q, float n0, float n1) {
+    // dp_core.pyx:259-260, evaluated in double like the generated C, stored to float
+    return (float)((((2.0 * (double)p) * (double)q) * (1.0 - (double)sumx)) / ((1e-6 + (double)n0) + (double)n1));
+}
+
+// ------------------------------------------------------------------------------ dense costs
+struct DenseArgs {
+    const void* v0;  // [s0][d] rows of the chosen layer
+    const void* v1;
+    int s0, s1, d;
+    const float* inv0;  // [s0] or null
+    const float* inv1;
+    const float* n0;  // [s0]
+    const float* n1;
+    int mul0, mul1;  // (offset0+1), (offset1+1)
+    float* costs;    // [s0][s1]
+};
+
+template <typename E>
+__device__ void dense_block(const DenseArgs& g, int bx, int by, char* smem) {
+    using S = typename E::storage;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // 4 waves: 2x2 tiles of 16
+    const char** rowptr = reinterpret_cast<const char**>(smem);    // 64 rows
+    char* slab = smem + 64 * sizeof(char*);
+    const int x0 = bx * 32, y0 = by * 32;
+    if (tid < 64) {
+        const int side = tid >> 5, loc = tid & 31;
+        const int gi = (side ? y0 : x0) + loc;
+        const int nn = side ? g.s1 : g.s0;
+        const char* base = reinterpret_cast<const char*>(side ? g.v1 : g.v0);
+        rowptr[tid] = (gi < nn) ? base + (size_t)gi * g.d * sizeof(S) : nullptr;
+    }
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const int xt = wave >> 1, yt = wave & 1;
+    for (int k0 = 0; k0 < g.d; k0 += Mma<E>::KS) {
+        __syncthreads();
+        stage_slab<E>(slab, rowptr, 64, k0, g.d, tid, blockDim.x);
+        __syncthreads();
+        const char* ap = slab + xt * 16 * RS + Mma<E>::lane_off(lane);
+        const char* bp = slab + (32 + yt * 16) * RS + Mma<E>::lane_off(lane);
+#pragma unroll
+        for (int ks = 0; ks < Mma<E>::NK; ks++)
+            Mma<E>::mma(acc, Mma<E>::load(ap + ks * Mma<E>::KSTEP_BYTES), Mma<E>::load(bp + ks * Mma<E>::KSTEP_BYTES));
+    }
+    const int y = y0 + yt * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int x = x0 + xt * 16 + (lane >> 4) * 4 + r;
+        if (x < g.s0 && y < g.s1) {
+            float sumx = acc[r];
+            if (g.inv0) sumx = sumx * g.inv0[x] * g.inv1[y];
+            float c = cost_formula(sumx, 1, 1, g.n0[x], g.n1[y]);
+            c = (c * (float)g.mul0) * (float)g.mul1;  // dp_core.pyx:75 (float * int)
+            g.costs[(size_t)x * g.s1 + y] = c;
+        }
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void k_dense_costs(DenseArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    dense_block<E>(g, blockIdx.x, blockIdx.y, smem);
+}
+
+template <typename E, bool LV0>
+__global__ __launch_bounds__(256) void k_dense_costs_batch(const SvxPairDev* __restrict__ pairs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SvxPairDev& P = pairs[blockIdx.z];
+    if ((P.L == 0) != LV0) return;
+    const SvxLevel& Lv = P.lev[P.L];
+    DenseArgs g;
+    g.s0 = Lv.n[0];
+    g.s1 = Lv.n[1];
+    if ((int)blockIdx.x * 32 >= g.s0 || (int)blockIdx.y * 32 >= g.s1) return;
+    g.d = P.d;
+    g.v0 = LV0 ? P.v[0] : (const void*)Lv.P[0];
+    g.v1 = LV0 ? P.v[1] : (const void*)Lv.P[1];
+    g.inv0 = LV0 ? Lv.inv[0] : nullptr;
+    g.inv1 = LV0 ? Lv.inv[1] : nullptr;
+    g.n0 = Lv.nrm[0];
+    g.n1 = Lv.nrm[1];
+    g.mul0 = 1;
+    g.mul1 = 1;
+    g.costs = P.dcost;
+    dense_block<E>(g, blockIdx.x, blockIdx.y, smem);
+}
+
+// ------------------------------------------------------------------------------ score_path
+template <typename E, int NCH>
+__device__ __forceinline__ float row_dot(const typename E::storage* a, const typename E::storage* b, int d, int lane) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int col = (c * SVX_WAVE + lane) * E::VEC;
+        if (col < d) {
+            float x[E::VEC], y[E::VEC];
+            load_piece<E>(a + col, x);
+            load_piece<E>(b + col, y);
+#pragma unroll
+            for (int i = 0; i < E::VEC; i++) s += x[i] * y[i];
+        }
+    }
+    return wave_sum(s);
+}
+
+struct ScoreArgs {
+    const void* v1;  // [rows][d]
+    const void* v2;
+    const float* inv1;  // or null
+    const float* inv2;
+    const float* n1;
+    const float* n2;
+    const int* xx;
+    const int* yy;
+    int64_t n;
+    int rows1, rows2, d;
+    float* out;
+};
+
+template <typename E, int NCH>
+__device__ void score_block(const ScoreArgs& g, int64_t first, int64_t stride) {
+    using S = typename E::storage;
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = first; i < g.n; i += stride) {
+        int xi = g.xx[i], yi = g.yy[i];
+        xi = xi < 0 ? 0 : (xi >= g.rows1 ? g.rows1 - 1 : xi);  // validated on the host; never fault
+        yi = yi < 0 ? 0 : (yi >= g.rows2 ? g.rows2 - 1 : yi);
+        float dot = row_dot<E, NCH>(reinterpret_cast<const S*>(g.v1) + (size_t)xi * g.d,
+                                    reinterpret_cast<const S*>(g.v2) + (size_t)yi * g.d, g.d, lane);
+        if (lane == 0) {
+            if (g.inv1) dot = dot * g.inv1[xi] * g.inv2[yi];
+            const float den = g.n1[xi] + g.n2[yi];  // float add, no epsilon (dp_core.pyx:161)
+            g.out[i] = (float)((2.0 * (1.0 - (double)dot)) / (double)den);
+        }
+    }
+}
+
+template <typename E, int NCH>
+__global__ __launch_bounds__(256) void k_score_path(ScoreArgs g) {
+    score_block<E, NCH>(g, (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), (int64_t)gridDim.x * 4);
+}
+
+// level = blockIdx.y + (LV0 ? 0 : 1)
+template <typename E, int NCH, bool LV0>
+__global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restrict__ pairs) {
+    const SvxPairDev& P = pairs[blockIdx.z];
+    const int level = LV0 ? 0 : (int)blockIdx.y + 1;
+    if (level > P.L) return;
+    const SvxLevel& Lv = P.lev[level];
+    ScoreArgs g;
+    g.v1 = LV0 ? P.v[0] : (const void*)Lv.P[0];
+    g.v2 = LV0 ? P.v[1] : (const void*)Lv.P[1];
+    g.inv1 = LV0 ? Lv.inv[0] : nullptr;
+    g.inv2 = LV0 ? Lv.inv[1] : nullptr;
+    g.n1 = Lv.nrm[0];
+    g.n2 = Lv.nrm[1];
+    g.xx = Lv.kx;
+    g.yy = Lv.ky;
+    g.n = Lv.kn;
+    g.rows1 = Lv.n[0];
+    g.rows2 = Lv.n[1];
+    g.d = P.d;
+    g.out = Lv.kscore;
+    score_block<E, NCH>(g, (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), (int64_t)gridDim.x * 4);
+}
+
+// ------------------------------------------------------------------------------ band costs
+constexpr int TA = SVX_BC_TA, TB = SVX_BC_TB, ROWS = SVX_BC_ROWS;
+constexpr int BC_THREADS = 512;
+constexpr int TPW = 2;                         // types per wave per pass
+constexpr int TPP = (BC_THREADS / 64) * TPW;   // types per pass
+
+struct BandArgs {
+    const void* v0;  // [k0][n][d]
+    const void* v1;
+    int n, m, d;
+    const float* inv0;  // [k][n] or null
+    const float* inv1;
+    const float* nrm0;  // [k][n]
+    const float* nrm1;
+    const int* path;  // [A][2]
+    int A, W;
+    float* costs;  // [T][A][2W]
+    int* boff;     // [A]
+    int* status;   // set to SVX_ERR_PATH when the path is not a unit-step lattice path
+};
+
+__host__ __device__ inline size_t band_smem_bytes(int kx, int ky) {
+    size_t hdr = 2 * TA * sizeof(int) + (size_t)(kx + ky) * ROWS * sizeof(char*);
+    hdr = (hdr + 15) & ~(size_t)15;
+    size_t slab = (size_t)(kx + ky) * ROWS * RS;
+    size_t fs = (size_t)TPP * TA * TB * sizeof(float);
+    return hdr + (slab > fs ? slab : fs);
+}
+
+template <typename E>
+__device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky, int chunk_a, int chunk_b, char* smem) {
+    using S = typename E::storage;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = 2 * g.W;
+    const int a0 = chunk_a * TA;
+    const int TAe = (g.A - a0) < TA ? (g.A - a0) : TA;
+    const int b0 = chunk_b * TB;
+    const int TBe = (B - b0) < TB ? (B - b0) : TB;
+    int* spx = reinterpret_cast<int*>(smem);
+    int* spy = spx + TA;
+    const char** rowptr = reinterpret_cast<const char**>(smem + 2 * TA * sizeof(int));
+    const int NR = (kx + ky) * ROWS;
+    size_t hdr = 2 * TA * sizeof(int) + (size_t)NR * sizeof(char*);
+    hdr = (hdr + 15) & ~(size_t)15;
+    char* slab = smem + hdr;
+    float* Fs = reinterpret_cast<float*>(slab);  // aliases the slab after the k loop
+
+    if (tid < TAe) {
+        spx[tid] = g.path[2 * (a0 + tid)];
+        spy[tid] = g.path[2 * (a0 + tid) + 1];
+    }
+    __syncthreads();
+    if (tid < TAe) {
+        bool ok = (spx[tid] + spy[tid] == a0 + tid);
+        if (tid > 0) ok = ok && spx[tid] >= spx[tid - 1] && spy[tid] >= spy[tid - 1];
+        if (!ok && g.status) *g.status = SVX_ERR_PATH;
+        if (chunk_b == 0) g.boff[a0 + tid] = spy[tid] - g.W;
+    }
+    const int xlo = spx[0], ylo = spy[0];
+    const int X0 = xlo + g.W - (b0 + TBe - 1);
+    const int Y0 = ylo - g.W + b0;
+    for (int r = tid; r < NR; r += BC_THREADS) {
+        const int side = r >= kx * ROWS;
+        const int rr = side ? r - kx * ROWS : r;
+        const int layer = rr / ROWS, loc = rr % ROWS;
+        const int gi = (side ? Y0 : X0) + loc;
+        const int nn = side ? g.m : g.n;
+        const char* base = reinterpret_cast<const char*>(side ? g.v1 : g.v0);
+        rowptr[r] = (gi >= 0 && gi < nn) ? base + ((size_t)layer * nn + gi) * g.d * sizeof(S) : nullptr;
+    }
+
+    for (int pass = 0; pass * TPP < ty.n; pass++) {
+        const int t0 = pass * TPP + wave * TPW;
+        f32x4_t acc[TPW][9];
+#pragma unroll
+        for (int ti = 0; ti < TPW; ti++)
+#pragma unroll
+            for (int j = 0; j < 9; j++) acc[ti][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        int xb[TPW], yb[TPW];
+        const int loff = Mma<E>::lane_off(lane);
+#pragma unroll
+        for (int ti = 0; ti < TPW; ti++) {
+            const int t = t0 + ti;
+            xb[ti] = (t < ty.n) ? (ty.x[t] - 1) * ROWS : 0;
+            yb[ti] = (t < ty.n) ? (kx + ty.y[t] - 1) * ROWS : 0;
+        }
+        for (int k0 = 0; k0 < g.d; k0 += Mma<E>::KS) {
+            __syncthreads();
+            stage_slab<E>(slab, rowptr, NR, k0, g.d, tid, BC_THREADS);
+            __syncthreads();
+#pragma unroll
+            for (int ti = 0; ti < TPW; ti++) {
+                if (t0 + ti < ty.n) {  // wave-uniform
+                    const char* ap = slab + xb[ti] * RS + loff;
+                    const char* bp = slab + yb[ti] * RS + loff;
+#pragma unroll
+                    for (int ks = 0; ks < Mma<E>::NK; ks++) {
+                        typename Mma<E>::frag fa[3], fb[3];
+#pragma unroll
+                        for (int j = 0; j < 3; j++) {
+                            fa[j] = Mma<E>::load(ap + j * 16 * RS + ks * Mma<E>::KSTEP_BYTES);
+                            fb[j] = Mma<E>::load(bp + j * 16 * RS + ks * Mma<E>::KSTEP_BYTES);
+                        }
+#pragma unroll
+                        for (int xt = 0; xt < 3; xt++)
+#pragma unroll
+                            for (int yt = 0; yt < 3; yt++) Mma<E>::mma(acc[ti][xt * 3 + yt], fa[xt], fb[yt]);
+                    }
+                }
+            }
+        }
+        __syncthreads();  // all waves done reading the slab; Fs may overwrite it
+#pragma unroll
+        for (int ti = 0; ti < TPW; ti++) {
+            const int t = t0 + ti;
+            if (t < ty.n) {
+                const int p = ty.x[t], q = ty.y[t];
+                const float* n0 = g.nrm0 + (size_t)(p - 1) * g.n;
+                const float* n1 = g.nrm1 + (size_t)(q - 1) * g.m;
+                const float* i0 = g.inv0 ? g.inv0 + (size_t)(p - 1) * g.n : nullptr;
+                const float* i1 = g.inv1 ? g.inv1 + (size_t)(q - 1) * g.m : nullptr;
+                float* F = Fs + (size_t)(t - pass * TPP) * TA * TB;
+#pragma unroll
+                for (int xt = 0; xt < 3; xt++)
+#pragma unroll
+                    for (int yt = 0; yt < 3; yt++) {
+                        const int yy = Y0 + yt * 16 + (lane & 15);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int xx = X0 + xt * 16 + (lane >> 4) * 4 + r;
+                            const int ai = xx + yy - a0;
+                            if (ai >= 0 && ai < TAe) {
+                                const int bi = yy - (spy[ai] - g.W) - b0;
+                                if (bi >= 0 && bi < TBe) {
+                                    float c;
+                                    if (xx >= 0 && xx < g.n && yy >= 0 && yy < g.m) {
+                                        float sumx = acc[ti][xt * 3 + yt][r];
+                                        if (i0) sumx = sumx * i0[xx] * i1[yy];
+                                        c = cost_formula(sumx, p, q, n0[xx], n1[yy]);
+                                    } else {
+                                        c = __builtin_inff();
+                                    }
+                                    F[ai * TB + bi] = c;
+                                }
+                            }
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+        // coalesced write-out of the [type][a][b] block
+        const int ntp = (ty.n - pass * TPP) < TPP ? (ty.n - pass * TPP) : TPP;
+        const int per = TAe * TBe;
+        for (int idx = tid; idx < ntp * per; idx += BC_THREADS) {
+            const int tl = idx / per, rem = idx % per;
+            const int ai = rem / TBe, bi = rem % TBe;
+            g.costs[((size_t)(pass * TPP + tl) * g.A + (a0 + ai)) * B + (b0 + bi)] = Fs[((size_t)tl * TA + ai) * TB + bi];
+        }
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(BC_THREADS) void k_band_costs(BandArgs g, SvxTypes ty, int kx, int ky, int nchunk_b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    band_block<E>(g, ty, kx, ky, blockIdx.x / nchunk_b, blockIdx.x % nchunk_b, smem);
+}
+
+// depth 0 uses the final types on the raw rows; deeper levels use (1,1) on normalised fp32 layer 0
+template <typename E, bool LV0>
+__global__ __launch_bounds__(BC_THREADS) void k_band_costs_batch(const SvxPairDev* __restrict__ pairs, int depth, SvxTypes ty,
+                                                                 int kx, int ky, int W, int nchunk_b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SvxPairDev& P = pairs[blockIdx.y];
+    if (depth > P.L || (depth == P.L && P.L > 0)) return;  // refined levels only (or level 0 when L == 0)
+    const SvxLevel& Lv = P.lev[depth];
+    BandArgs g;
+    g.A = *Lv.path_len;
+    const int chunk_a = blockIdx.x / nchunk_b;
+    if (g.A <= 0 || chunk_a * TA >= g.A) return;
+    g.n = Lv.n[0];
+    g.m = Lv.n[1];
+    g.d = P.d;
+    g.v0 = LV0 ? P.v[0] : (const void*)Lv.P[0];
+    g.v1 = LV0 ? P.v[1] : (const void*)Lv.P[1];
+    g.inv0 = LV0 ? Lv.inv[0] : nullptr;
+    g.inv1 = LV0 ? Lv.inv[1] : nullptr;
+    g.nrm0 = Lv.nrm[0];
+    g.nrm1 = Lv.nrm[1];
+    g.path = Lv.path;
+    g.W = W;
+    g.costs = Lv.costs;
+    g.boff = Lv.boff;
+    g.status = P.status;
+    band_block<E>(g, ty, kx, ky, chunk_a, blockIdx.x % nchunk_b, smem);
+}
+
+inline int nch_f32(int d) {
+    int c = (d + 255) / 256;
+    return c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : 8;
+}
+inline int nch_16(int d) {
+    int c = (d + 511) / 512;
+    return c <= 1 ? 1 : c <= 2 ? 2 : 4;
+}
+
+constexpr size_t DENSE_SMEM = 64 * sizeof(char*) + 64 * RS;
+
+}  // namespace
+
+int svxl_dense_costs(svx_ctx* ctx, const float* v0, int s0, const float* v1, int s1, int d, const float* n0,
+                     const float* n1, int mul0, int mul1, float* costs) {
+    if (s0 <= 0 || s1 <= 0) return SVX_OK;
+    DenseArgs g{v0, v1, s0, s1, d, nullptr, nullptr, n0, n1, mul0, mul1, costs};
+    hipLaunchKernelGGL(k_dense_costs<ElemF32>, dim3((s0 + 31) / 32, (s1 + 31) / 32), dim3(256), DENSE_SMEM, ctx->stream, g);
+    SVX_LAUNCH_CHECK(ctx, "k_dense_costs");
+    return SVX_OK;
+}
+
+int svxl_dense_costs_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int max_s0, int max_s1, int dtype, int d) {
+    (void)d;
+    if (n_pairs <= 0 || max_s0 <= 0 || max_s1 <= 0) return SVX_OK;
+    dim3 grid((max_s0 + 31) / 32, (max_s1 + 31) / 32, n_pairs);
+    hipLaunchKernelGGL((k_dense_costs_batch<ElemF32, false>), grid, dim3(256), DENSE_SMEM, ctx->stream, pairs);
+    if (dtype == SVX_F32)
+        hipLaunchKernelGGL((k_dense_costs_batch<ElemF32, true>), grid, dim3(256), DENSE_SMEM, ctx->stream, pairs);
+    else if (dtype == SVX_F16)
+        hipLaunchKernelGGL((k_dense_costs_batch<ElemF16, true>), grid, dim3(256), DENSE_SMEM, ctx->stream, pairs);
+    else
+        hipLaunchKernelGGL((k_dense_costs_batch<ElemBF16, true>), grid, dim3(256), DENSE_SMEM, ctx->stream, pairs);
+    SVX_LAUNCH_CHECK(ctx, "k_dense_costs_batch");
+    return SVX_OK;
+}
+
+int svxl_score_path(svx_ctx* ctx, const int* xx, const int* yy, int64_t n, const float* n1, const float* n2,
+                    const float* v1, int rows1, const float* v2, int rows2, int d, float* out) {
+    if (n <= 0) return SVX_OK;
+    ScoreArgs g{v1, v2, nullptr, nullptr, n1, n2, xx, yy, n, rows1, rows2, d, out};
+    int64_t nb = (n + 3) / 4;
+    if (nb > 16384) nb = 16384;
+#define M(N) hipLaunchKernelGGL((k_score_path<ElemF32, N>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, g)
+    switch (nch_f32(d)) {
+        case 1: M(1); break;
+        case 2: M(2); break;
+        case 4: M(4); break;
+        default: M(8); break;
+    }
+#undef M
+    SVX_LAUNCH_CHECK(ctx, "k_score_path");
+    return SVX_OK;
+}
+
+int svxl_knob_scores(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int max_L, int max_kn, int dtype, int d) {
+    if (n_pairs <= 0 || max_kn <= 0) return SVX_OK;
+    int nb = (max_kn + 3) / 4;
+    if (nb > 2048) nb = 2048;
+    hipStream_t st = ctx->stream;
+#define M32(N, LV0, GY) hipLaunchKernelGGL((k_knob_scores<ElemF32, N, LV0>), dim3(nb, GY, n_pairs), dim3(256), 0, st, pairs)
+#define M16(E, N) hipLaunchKernelGGL((k_knob_scores<E, N, true>), dim3(nb, 1, n_pairs), dim3(256), 0, st, pairs)
+    if (max_L >= 1) {
+        switch (nch_f32(d)) {
+            case 1: M32(1, false, max_L); break;
+            case 2: M32(2, false, max_L); break;
+            case 4: M32(4, false, max_L); break;
+            default: M32(8, false, max_L); break;
+        }
+    }
+    if (dtype == SVX_F32) {
+        switch (nch_f32(d)) {
+            case 1: M32(1, true, 1); break;
+            case 2: M32(2, true, 1); break;
+            case 4: M32(4, true, 1); break;
+            default: M32(8, true, 1); break;
+        }
+    } else if (dtype == SVX_F16) {
+        switch (nch_16(d)) {
+            case 1: M16(ElemF16, 1); break;
+            case 2: M16(ElemF16, 2); break;
+            default: M16(ElemF16, 4); break;
+        }
+    } else {
+        switch (nch_16(d)) {
+            case 1: M16(ElemBF16, 1); break;
+            case 2: M16(ElemBF16, 2); break;
+            default: M16(ElemBF16, 4); break;
+        }
+    }
+#undef M32
+#undef M16
+    SVX_LAUNCH_CHECK(ctx, "k_knob_scores");
+    return SVX_OK;
+}
+
+static int types_layers(const SvxTypes& ty, int* kx, int* ky) {
+    int mx = 0, my = 0;
+    for (int t = 0; t < ty.n; t++) {
+        if (ty.x[t] > mx) mx = ty.x[t];
+        if (ty.y[t] > my) my = ty.y[t];
+    }
+    *kx = mx;
+    *ky = my;
+    return 0;
+}
+
+int svxl_band_costs(svx_ctx* ctx, const void* v0, int k0, int n, const void* v1, int k1, int m, int d, int dtype,
+                    const float* inv0, const float* inv1, const float* nrm0, const float* nrm1, const int* path, int A,
+                    const SvxTypes& types, int W, float* costs, int* boff, int* status) {
+    if (A <= 0) return SVX_OK;
+    int kx, ky;
+    types_layers(types, &kx, &ky);
+    if (kx > k0 || ky > k1) return svx_fail(ctx, SVX_ERR_OVERLAPS, "overlaps");
+    if (types.n == 0) {
+        // only b_offset is produced (costs has shape [0][A][B]); stage zero layers, zero passes
+        kx = 0;
+        ky = 0;
+    }
+    const size_t smem = band_smem_bytes(kx, ky);
+    if (smem > 160 * 1024) return svx_fail(ctx, SVX_ERR_ARG, "band costs: %d+%d overlap layers need %zu bytes of LDS (>160 KiB)", kx, ky, smem);
+    const int B = 2 * W;
+    const int nca = (A + TA - 1) / TA, ncb = (B + TB - 1) / TB;
+    BandArgs g{v0, v1, n, m, d, inv0, inv1, nrm0, nrm1, path, A, W, costs, boff, status};
+    dim3 grid((unsigned)(nca * ncb));
+#define LAUNCH(E)                                                                                                   \
+    do {                                                                                                            \
+        if (smem > 64 * 1024)                                                                                       \
+            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_band_costs<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL(k_band_costs<E>, grid, dim3(BC_THREADS), smem, ctx->stream, g, types, kx, ky, ncb);      \
+    } while (0)
+    if (dtype == SVX_F32) LAUNCH(ElemF32);
+    else if (dtype == SVX_F16) LAUNCH(ElemF16);
+    else LAUNCH(ElemBF16);
+#undef LAUNCH
+    SVX_LAUNCH_CHECK(ctx, "k_band_costs");
+    return SVX_OK;
+}
+
+int svxl_band_costs_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int depth, int max_A, const SvxTypes& types,
+                          int W, int dtype, int d) {
+    (void)d;
+    if (n_pairs <= 0 || max_A <= 0) return SVX_OK;
+    int kx, ky;
+    types_layers(types, &kx, &ky);
+    if (types.n == 0) kx = ky = 0;
+    const size_t smem = band_smem_bytes(kx, ky);
+    if (smem > 160 * 1024) return svx_fail(ctx, SVX_ERR_ARG, "band costs: %d+%d overlap layers need %zu bytes of LDS (>160 KiB)", kx, ky, smem);
+    const int B = 2 * W;
+    const int nca = (max_A + TA - 1) / TA, ncb = (B + TB - 1) / TB;
+    dim3 grid((unsigned)(nca * ncb), n_pairs);
+#define LAUNCH(E, LV0)                                                                                              \
+    do {                                                                                                            \
+        if (smem > 64 * 1024)                                                                                       \
+            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_band_costs_batch<E, LV0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_band_costs_batch<E, LV0>), grid, dim3(BC_THREADS), smem, ctx->stream, pairs, depth, types, kx, ky, W, ncb); \
+    } while (0)
+    if (depth > 0) LAUNCH(ElemF32, false);
+    else if (dtype == SVX_F32) LAUNCH(ElemF32, true);
+    else if (dtype == SVX_F16) LAUNCH(ElemF16, true);
+    else LAUNCH(ElemBF16, true);
+#undef LAUNCH
+    SVX_LAUNCH_CHECK(ctx, "k_band_costs_batch");
+    return SVX_OK;
+}

@@ -1,0 +1,515 @@
+// svx_rows.hip -- row-streaming kernels: unit-normalisation, pyramid down-sampling, column
+// means, sampled-row means and the per-row normalisers ("norms") of dp_utils.py.
+//
+// All of these are HBM-bound streams over [layers][rows][d] tensors.  One wave owns one row at a
+// time: lane l holds the 16-byte pieces (chunk*64 + l) of the row, so every wave-instruction
+// moves one contiguous KiB; reductions over d are wave butterflies, nothing goes through LDS
+// except the per-workgroup column-sum hand-off.
+//
+// Reference semantics (paths relative to the reference repository):
+//   make_norm1            svecalign/vecalign/dp_utils.py:32-40
+//   downsample_vectors    svecalign/vecalign/dp_utils.py:362-378
+//   compute_norms         svecalign/vecalign/dp_utils.py:326-359
+// compute_norms is evaluated as 1 - <row, mean_s(sample_s)> (one dot per row instead of one
+// GEMM column per sample); the two are equal in exact arithmetic and agree to ~1e-7 in float32.
+#include "svx_common.h"
+
+namespace {
+
+template <typename E, int NCH>
+struct Row {
+    static constexpr int VEC = E::VEC;
+    static constexpr int EPL = NCH * VEC;  // elements per lane
+    using S = typename E::storage;
+
+    __device__ static __forceinline__ void load(const S* row, int d, int lane, float* x) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            int col = (c * SVX_WAVE + lane) * VEC;
+            if (col < d) {
+                load_piece<E>(row + col, x + c * VEC);
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; i++) x[c * VEC + i] = 0.f;
+            }
+        }
+    }
+    // float32 vector (mean / rbar / output rows) addressed with the same column map
+    __device__ static __forceinline__ void loadf(const float* v, int d, int lane, float* x) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            int col = (c * SVX_WAVE + lane) * VEC;
+            if (col < d) {
+#pragma unroll
+                for (int q = 0; q < VEC / 4; q++) {
+                    float4 t = *reinterpret_cast<const float4*>(v + col + 4 * q);
+                    x[c * VEC + 4 * q + 0] = t.x; x[c * VEC + 4 * q + 1] = t.y;
+                    x[c * VEC + 4 * q + 2] = t.z; x[c * VEC + 4 * q + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; i++) x[c * VEC + i] = 0.f;
+            }
+        }
+    }
+    __device__ static __forceinline__ void storef(float* v, int d, int lane, const float* x) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            int col = (c * SVX_WAVE + lane) * VEC;
+            if (col < d) {
+#pragma unroll
+                for (int q = 0; q < VEC / 4; q++) {
+                    float4 t = make_float4(x[c * VEC + 4 * q + 0], x[c * VEC + 4 * q + 1], x[c * VEC + 4 * q + 2],
+                                           x[c * VEC + 4 * q + 3]);
+                    *reinterpret_cast<float4*>(v + col + 4 * q) = t;
+                }
+            }
+        }
+    }
+    // lane-register index e  ->  column
+    __device__ static __forceinline__ int col_of(int e, int lane) {
+        return ((e / VEC) * SVX_WAVE + lane) * VEC + (e % VEC);
+    }
+};
+
+// One workgroup (4 waves) walks SVX_PYR_SLOTS row-pair slots of one layer:
+//   x = row - mean (if mean); den = ||x|| + 1e-5; vn = x / den            (make_norm1)
+//   nrm = 1 - <vn, rbar>                                                   (compute_norms)
+//   next[slot] = vn[2 slot] + vn[2 slot + 1]; part = column sums of next   (downsample_vectors)
+template <typename E, int NCH>
+__device__ void pyr_block(const typename E::storage* rows, int n, int d, const float* mean, const float* rbar,
+                          float* inv_out, float* nrm_out, float* vn_out, float* next, float* part_out, int blk,
+                          float* lds) {
+    // lds: [2][NCH*VEC*64] floats for mean / rbar (zero padded), then [4][EPL][64] for the partials
+    using R = Row<E, NCH>;
+    constexpr int EPL = R::EPL;
+    constexpr int DP = EPL * SVX_WAVE;  // padded row length
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* mu_l = lds;
+    float* rb_l = lds + DP;
+    float* red = lds + 2 * DP;
+    for (int c = threadIdx.x; c < DP; c += blockDim.x) {
+        mu_l[c] = (mean && c < d) ? mean[c] : 0.f;
+        rb_l[c] = (rbar && c < d) ? rbar[c] : 0.f;
+    }
+    __syncthreads();
+    float cs[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) cs[e] = 0.f;
+    const int nslots = (n + 1) / 2;
+    const int slot0 = blk * SVX_PYR_SLOTS + w * (SVX_PYR_SLOTS / 4);
+#pragma unroll 1
+    for (int i = 0; i < SVX_PYR_SLOTS / 4; i++) {
+        const int jp = slot0 + i;
+        if (jp >= nslots) break;  // wave-uniform
+        float xs[EPL];            // running pair sum
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            const int r = 2 * jp + half;
+            if (r >= n) break;  // wave-uniform; only the odd tail row has no partner
+            float x[EPL];
+            R::load(rows + (size_t)r * d, d, lane, x);
+            if (mean) {
+                float mu[EPL];
+                R::loadf(mu_l, DP, lane, mu);
+#pragma unroll
+                for (int e = 0; e < EPL; e++) x[e] = x[e] - mu[e];  // columns >= d: 0 - 0
+            }
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; e++) ss += x[e] * x[e];
+            ss = wave_sum(ss);
+            const float den = sqrtf(ss) + 1e-5f;
+#pragma unroll
+            for (int e = 0; e < EPL; e++) x[e] = x[e] / den;
+            if (rbar) {
+                float rb[EPL];
+                R::loadf(rb_l, DP, lane, rb);
+                float dt = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; e++) dt += x[e] * rb[e];
+                dt = wave_sum(dt);
+                if (lane == 0 && nrm_out) nrm_out[r] = 1.0f - dt;
+            }
+            if (lane == 0 && inv_out) inv_out[r] = 1.0f / den;
+            if (vn_out) R::storef(vn_out + (size_t)r * d, d, lane, x);
+            if (next) {
+                if (half == 0) {
+#pragma unroll
+                    for (int e = 0; e < EPL; e++) xs[e] = x[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPL; e++) {
+                        xs[e] = xs[e] + x[e];
+                        cs[e] += xs[e];
+                    }
+                    R::storef(next + (size_t)jp * d, d, lane, xs);
+                }
+            }
+        }
+    }
+    if (part_out) {
+        // fixed-order reduction over the 4 waves -> deterministic partial
+#pragma unroll
+        for (int e = 0; e < EPL; e++) red[(w * EPL + e) * SVX_WAVE + lane] = cs[e];
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < EPL * SVX_WAVE; idx += blockDim.x) {
+            const int e = idx / SVX_WAVE, l = idx % SVX_WAVE;
+            const int col = R::col_of(e, l);
+            if (col < d) {
+                float s = red[(0 * EPL + e) * SVX_WAVE + l];
+                s += red[(1 * EPL + e) * SVX_WAVE + l];
+                s += red[(2 * EPL + e) * SVX_WAVE + l];
+                s += red[(3 * EPL + e) * SVX_WAVE + l];
+                part_out[col] = s;
+            }
+        }
+    }
+}
+
+// Mean of K*S sampled rows (optionally mean-subtracted and unit-normalised first).
+template <typename E, int NCH>
+__device__ void sample_mean_block(const typename E::storage* base, int K, int n, int d, const int* idx, int S,
+                                  const float* mean /*[K][d] or null*/, bool normalize, float* rbar, float* lds) {
+    using R = Row<E, NCH>;
+    constexpr int EPL = R::EPL;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) acc[e] = 0.f;
+    const int total = K * S;
+#pragma unroll 1
+    for (int i = w; i < total; i += 4) {
+        const int k = i / S;
+        int r = idx[i];
+        r = r < 0 ? 0 : (r >= n ? n - 1 : r);  // indices are validated on the host; never fault
+        float x[EPL];
+        R::load(base + ((size_t)k * n + r) * d, d, lane, x);
+        if (mean) {
+            float mu[EPL];
+            R::loadf(mean + (size_t)k * d, d, lane, mu);
+#pragma unroll
+            for (int e = 0; e < EPL; e++) x[e] = x[e] - mu[e];
+        }
+        if (normalize) {
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; e++) ss += x[e] * x[e];
+            ss = wave_sum(ss);
+            const float den = sqrtf(ss) + 1e-5f;
+#pragma unroll
+            for (int e = 0; e < EPL; e++) x[e] = x[e] / den;
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; e++) acc[e] += x[e];
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; e++) lds[(w * EPL + e) * SVX_WAVE + lane] = acc[e];
+    __syncthreads();
+    for (int i2 = threadIdx.x; i2 < EPL * SVX_WAVE; i2 += blockDim.x) {
+        const int e = i2 / SVX_WAVE, l = i2 % SVX_WAVE;
+        const int col = R::col_of(e, l);
+        if (col < d) {
+            float s = lds[(0 * EPL + e) * SVX_WAVE + l];
+            s += lds[(1 * EPL + e) * SVX_WAVE + l];
+            s += lds[(2 * EPL + e) * SVX_WAVE + l];
+            s += lds[(3 * EPL + e) * SVX_WAVE + l];
+            rbar[col] = s / (float)total;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- fused-pipeline kernels
+template <typename E, int NCH, bool LV0>
+__global__ __launch_bounds__(256) void k_pyramid(const SvxPairDev* __restrict__ pairs, int level) {
+    __shared__ float lds[6 * NCH * E::VEC * SVX_WAVE];
+    const SvxPairDev& P = pairs[blockIdx.z];
+    if (level > P.L) return;
+    int side, k;
+    if ((int)blockIdx.y < P.K[0]) {
+        side = 0;
+        k = blockIdx.y;
+    } else {
+        side = 1;
+        k = blockIdx.y - P.K[0];
+        if (k >= P.K[1]) return;
+    }
+    const SvxLevel& Lv = P.lev[level];
+    if ((int)blockIdx.x >= Lv.nblk[side]) return;
+    const int n = Lv.n[side], d = P.d;
+    using S = typename E::storage;
+    const S* rows = LV0 ? reinterpret_cast<const S*>(P.v[side]) + (size_t)k * n * d
+                        : reinterpret_cast<const S*>(Lv.P[side] + (size_t)k * n * d);
+    const float* mean = LV0 ? nullptr : Lv.mean[side] + (size_t)k * d;
+    const bool want_nrm = !(LV0 && P.norm_override[side]);
+    const float* rbar = want_nrm ? Lv.rbar[1 - side] : nullptr;
+    float* inv_out = LV0 ? Lv.inv[side] + (size_t)k * n : nullptr;
+    float* nrm_out = want_nrm ? Lv.nrm[side] + (size_t)k * n : nullptr;
+    float* vn_out = (!LV0 && k == 0) ? Lv.P[side] : nullptr;  // layer 0 is normalised in place
+    const bool has_next = level < P.L;
+    float* next = has_next ? P.lev[level + 1].P[side] + (size_t)k * (n / 2) * d : nullptr;
+    float* part = has_next ? P.lev[level + 1].part[side] + ((size_t)k * Lv.nblk[side] + blockIdx.x) * d : nullptr;
+    pyr_block<E, NCH>(rows, n, d, mean, rbar, inv_out, nrm_out, vn_out, next, part, blockIdx.x, lds);
+}
+
+__global__ __launch_bounds__(256) void k_colmean(const SvxPairDev* __restrict__ pairs, int level) {
+    const SvxPairDev& P = pairs[blockIdx.z];
+    if (level > P.L || level < 1) return;
+    int side, k;
+    if ((int)blockIdx.y < P.K[0]) {
+        side = 0;
+        k = blockIdx.y;
+    } else {
+        side = 1;
+        k = blockIdx.y - P.K[0];
+        if (k >= P.K[1]) return;
+    }
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.d) return;
+    const SvxLevel& Lv = P.lev[level];
+    const int np = Lv.npart[side];
+    const float* part = Lv.part[side] + (size_t)k * np * P.d;
+    float s = 0.f;
+    for (int b = 0; b < np; b++) s += part[(size_t)b * P.d + c];
+    Lv.mean[side][(size_t)k * P.d + c] = s / (float)Lv.n[side];
+}
+
+template <typename E, int NCH, bool LV0>
+__global__ __launch_bounds__(256) void k_sample_mean(const SvxPairDev* __restrict__ pairs, int level) {
+    __shared__ float lds[4 * NCH * E::VEC * SVX_WAVE];
+    const SvxPairDev& P = pairs[blockIdx.y];
+    if (level > P.L) return;
+    const int side = blockIdx.x;
+    const SvxLevel& Lv = P.lev[level];
+    if (Lv.S[side] <= 0 || Lv.sidx[side] == nullptr) return;
+    using S = typename E::storage;
+    const S* base = LV0 ? reinterpret_cast<const S*>(P.v[side]) : reinterpret_cast<const S*>(Lv.P[side]);
+    sample_mean_block<E, NCH>(base, P.K[side], Lv.n[side], P.d, Lv.sidx[side], Lv.S[side], LV0 ? nullptr : Lv.mean[side],
+                              true, Lv.rbar[side], lds);
+}
+
+// ---------------------------------------------------------------- per-op (plain pointer) kernels
+template <int NCH>
+__global__ __launch_bounds__(256) void k_norm1_plain(float* vecs, int64_t rows, int d, const float* mean) {
+    // make_norm1 over a flat [rows][d] tensor, in place; treats consecutive rows as pair slots
+    __shared__ float lds[6 * NCH * 4 * SVX_WAVE];
+    int64_t nslots_total = (rows + 1) / 2;
+    int64_t blk = blockIdx.x;
+    if (blk * SVX_PYR_SLOTS >= nslots_total) return;
+    // pyr_block indexes rows with int: hand it a window of at most 2*SVX_PYR_SLOTS rows
+    int64_t row0 = blk * 2 * SVX_PYR_SLOTS;
+    int n = (int)((rows - row0) < (int64_t)(2 * SVX_PYR_SLOTS) ? (rows - row0) : (int64_t)(2 * SVX_PYR_SLOTS));
+    float* base = vecs + row0 * d;
+    pyr_block<ElemF32, NCH>(base, n, d, mean, nullptr, nullptr, nullptr, base, nullptr, nullptr, 0, lds);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void k_pairsum_plain(const float* vecs, int n, int d, float* half, float* part,
+                                                       int nblk) {
+    // grid (nblk, k): half[k][j] = vecs[k][2j] + vecs[k][2j+1]; part[k][blk] = column sums
+    using R = Row<ElemF32, NCH>;
+    constexpr int EPL = R::EPL;
+    __shared__ float lds[4 * EPL * SVX_WAVE];
+    const int k = blockIdx.y, blk = blockIdx.x;
+    const int h = n / 2;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* src = vecs + (size_t)k * n * d;
+    float* dst = half + (size_t)k * h * d;
+    float cs[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) cs[e] = 0.f;
+    const int slot0 = blk * SVX_PYR_SLOTS + w * (SVX_PYR_SLOTS / 4);
+#pragma unroll 1
+    for (int i = 0; i < SVX_PYR_SLOTS / 4; i++) {
+        const int j = slot0 + i;
+        if (j >= h) break;
+        float xa[EPL], xb[EPL];
+        R::load(src + (size_t)(2 * j) * d, d, lane, xa);
+        R::load(src + (size_t)(2 * j + 1) * d, d, lane, xb);
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            xa[e] = xa[e] + xb[e];
+            cs[e] += xa[e];
+        }
+        R::storef(dst + (size_t)j * d, d, lane, xa);
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; e++) lds[(w * EPL + e) * SVX_WAVE + lane] = cs[e];
+    __syncthreads();
+    float* po = part + ((size_t)k * nblk + blk) * d;
+    for (int idx = threadIdx.x; idx < EPL * SVX_WAVE; idx += blockDim.x) {
+        const int e = idx / SVX_WAVE, l = idx % SVX_WAVE;
+        const int col = R::col_of(e, l);
+        if (col < d) {
+            float s = lds[(0 * EPL + e) * SVX_WAVE + l];
+            s += lds[(1 * EPL + e) * SVX_WAVE + l];
+            s += lds[(2 * EPL + e) * SVX_WAVE + l];
+            s += lds[(3 * EPL + e) * SVX_WAVE + l];
+            po[col] = s;
+        }
+    }
+}
+
+__global__ void k_colmean_plain(const float* part, int nblk, int d, int count, float* mean) {
+    // grid (ceil(d/256), k)
+    const int k = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    const float* p = part + (size_t)k * nblk * d;
+    float s = 0.f;
+    for (int b = 0; b < nblk; b++) s += p[(size_t)b * d + c];
+    mean[(size_t)k * d + c] = s / (float)count;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void k_subnorm_plain(float* half, int h, int d, const float* mean) {
+    // grid (nblk, k): half[k][j] = (half[k][j] - mean[k]) / (||.|| + 1e-5), in place
+    __shared__ float lds[6 * NCH * 4 * SVX_WAVE];
+    const int k = blockIdx.y;
+    float* base = half + (size_t)k * h * d;
+    pyr_block<ElemF32, NCH>(base, h, d, mean + (size_t)k * d, nullptr, nullptr, nullptr, base, nullptr, nullptr,
+                            blockIdx.x, lds);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void k_sample_mean_plain(const float* vecs, int K, int n, int d, const int* idx,
+                                                           int S, float* rbar) {
+    __shared__ float lds[4 * NCH * 4 * SVX_WAVE];
+    sample_mean_block<ElemF32, NCH>(vecs, K, n, d, idx, S, nullptr, false, rbar, lds);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void k_rownorms_plain(const float* vecs, int64_t rows, int d, const float* rbar,
+                                                        float* norms) {
+    using R = Row<ElemF32, NCH>;
+    constexpr int EPL = R::EPL;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float rb[EPL];
+    R::loadf(rbar, d, lane, rb);
+    for (int64_t r = (int64_t)blockIdx.x * 4 + w; r < rows; r += (int64_t)gridDim.x * 4) {
+        float x[EPL];
+        R::load(vecs + r * d, d, lane, x);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) s += x[e] * rb[e];
+        s = wave_sum(s);
+        if (lane == 0) norms[r] = 1.0f - s;
+    }
+}
+
+inline int nch_f32(int d) {
+    int c = (d + 255) / 256;
+    return c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : 8;
+}
+inline int nch_16(int d) {
+    int c = (d + 511) / 512;
+    return c <= 1 ? 1 : c <= 2 ? 2 : 4;
+}
+
+}  // namespace
+
+#define SVX_SWITCH_NCH_F32(d, M) \
+    switch (nch_f32(d)) {        \
+        case 1: M(1); break;     \
+        case 2: M(2); break;     \
+        case 4: M(4); break;     \
+        default: M(8); break;    \
+    }
+#define SVX_SWITCH_NCH_16(d, M) \
+    switch (nch_16(d)) {        \
+        case 1: M(1); break;    \
+        case 2: M(2); break;    \
+        default: M(4); break;   \
+    }
+
+int svxl_make_norm1(svx_ctx* ctx, float* vecs, int64_t rows, int d) {
+    if (rows <= 0) return SVX_OK;
+    int64_t nblk = ((rows + 1) / 2 + SVX_PYR_SLOTS - 1) / SVX_PYR_SLOTS;
+#define M(N) hipLaunchKernelGGL(k_norm1_plain<N>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, vecs, rows, d, (const float*)nullptr)
+    SVX_SWITCH_NCH_F32(d, M)
+#undef M
+    SVX_LAUNCH_CHECK(ctx, "k_norm1_plain");
+    return SVX_OK;
+}
+
+int svxl_pairsum(svx_ctx* ctx, const float* vecs, int k, int n, int d, float* half, float* part, int nblk) {
+    if (n / 2 <= 0 || k <= 0) return SVX_OK;
+#define M(N) hipLaunchKernelGGL(k_pairsum_plain<N>, dim3(nblk, k), dim3(256), 0, ctx->stream, vecs, n, d, half, part, nblk)
+    SVX_SWITCH_NCH_F32(d, M)
+#undef M
+    SVX_LAUNCH_CHECK(ctx, "k_pairsum_plain");
+    return SVX_OK;
+}
+
+int svxl_colmean_plain(svx_ctx* ctx, const float* part, int k, int nblk, int d, int count, float* mean) {
+    hipLaunchKernelGGL(k_colmean_plain, dim3((d + 255) / 256, k), dim3(256), 0, ctx->stream, part, nblk, d, count, mean);
+    SVX_LAUNCH_CHECK(ctx, "k_colmean_plain");
+    return SVX_OK;
+}
+
+int svxl_sub_mean(svx_ctx* ctx, float* half, int k, int h, int d, const float* mean) {
+    if (h <= 0) return SVX_OK;
+    int nblk = ((h + 1) / 2 + SVX_PYR_SLOTS - 1) / SVX_PYR_SLOTS;
+#define M(N) hipLaunchKernelGGL(k_subnorm_plain<N>, dim3(nblk, k), dim3(256), 0, ctx->stream, half, h, d, mean)
+    SVX_SWITCH_NCH_F32(d, M)
+#undef M
+    SVX_LAUNCH_CHECK(ctx, "k_subnorm_plain");
+    return SVX_OK;
+}
+
+int svxl_sample_mean_plain(svx_ctx* ctx, const float* vecs, int k, int n, int d, const int* idx, int S, float* rbar) {
+#define M(N) hipLaunchKernelGGL(k_sample_mean_plain<N>, dim3(1), dim3(256), 0, ctx->stream, vecs, k, n, d, idx, S, rbar)
+    SVX_SWITCH_NCH_F32(d, M)
+#undef M
+    SVX_LAUNCH_CHECK(ctx, "k_sample_mean_plain");
+    return SVX_OK;
+}
+
+int svxl_norms_from_rbar(svx_ctx* ctx, const float* vecs, int64_t rows, int d, const float* rbar, float* norms) {
+    if (rows <= 0) return SVX_OK;
+    int64_t nb = (rows + 3) / 4;
+    if (nb > 8192) nb = 8192;
+#define M(N) hipLaunchKernelGGL(k_rownorms_plain<N>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, vecs, rows, d, rbar, norms)
+    SVX_SWITCH_NCH_F32(d, M)
+#undef M
+    SVX_LAUNCH_CHECK(ctx, "k_rownorms_plain");
+    return SVX_OK;
+}
+
+// One pyramid level of the fused pipeline: (level >= 1: column means) -> sampled-row means ->
+// the streaming pass (norms, normalisers, normalised layer 0, pair sums for level+1).
+int svxl_pyramid_level(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int level, int dtype, int d, int max_nblk,
+                       int max_ksum, int max_npart) {
+    (void)max_npart;
+    if (n_pairs <= 0 || max_nblk <= 0) return SVX_OK;
+    hipStream_t st = ctx->stream;
+    if (level >= 1) {
+        hipLaunchKernelGGL(k_colmean, dim3((d + 255) / 256, max_ksum, n_pairs), dim3(256), 0, st, pairs, level);
+        SVX_LAUNCH_CHECK(ctx, "k_colmean");
+#define M(N)                                                                                                      \
+    hipLaunchKernelGGL((k_sample_mean<ElemF32, N, false>), dim3(2, n_pairs), dim3(256), 0, st, pairs, level);      \
+    hipLaunchKernelGGL((k_pyramid<ElemF32, N, false>), dim3(max_nblk, max_ksum, n_pairs), dim3(256), 0, st, pairs, level)
+        SVX_SWITCH_NCH_F32(d, M)
+#undef M
+    } else if (dtype == SVX_F32) {
+#define M(N)                                                                                                     \
+    hipLaunchKernelGGL((k_sample_mean<ElemF32, N, true>), dim3(2, n_pairs), dim3(256), 0, st, pairs, level);      \
+    hipLaunchKernelGGL((k_pyramid<ElemF32, N, true>), dim3(max_nblk, max_ksum, n_pairs), dim3(256), 0, st, pairs, level)
+        SVX_SWITCH_NCH_F32(d, M)
+#undef M
+    } else if (dtype == SVX_F16) {
+#define M(N)                                                                                                     \
+    hipLaunchKernelGGL((k_sample_mean<ElemF16, N, true>), dim3(2, n_pairs), dim3(256), 0, st, pairs, level);      \
+    hipLaunchKernelGGL((k_pyramid<ElemF16, N, true>), dim3(max_nblk, max_ksum, n_pairs), dim3(256), 0, st, pairs, level)
+        SVX_SWITCH_NCH_16(d, M)
+#undef M
+    } else {
+#define M(N)                                                                                                      \
+    hipLaunchKernelGGL((k_sample_mean<ElemBF16, N, true>), dim3(2, n_pairs), dim3(256), 0, st, pairs, level);      \
+    hipLaunchKernelGGL((k_pyramid<ElemBF16, N, true>), dim3(max_nblk, max_ksum, n_pairs), dim3(256), 0, st, pairs, level)
+        SVX_SWITCH_NCH_16(d, M)
+#undef M
+    }
+    SVX_LAUNCH_CHECK(ctx, "k_pyramid");
+    return SVX_OK;
+}

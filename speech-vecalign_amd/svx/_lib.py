@@ -1,0 +1,160 @@
+"""ctypes binding of libsvx.so (include/svx.h).  No CPU fallback: if the library or a GPU is
+missing, importing/creating a context raises."""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvx.so")
+
+SVX_F32, SVX_F16, SVX_BF16 = 0, 1, 2
+SVX_MAX_TYPES = 128
+SVX_MAX_LEVELS = 16
+
+SVX_OK, SVX_ERR_ARG, SVX_ERR_OVERLAPS, SVX_ERR_HIP, SVX_ERR_TRACEBACK = 0, 1, 2, 3, 4
+SVX_ERR_NOMEM, SVX_ERR_EXTEND, SVX_ERR_PATH, SVX_ERR_BP = 5, 6, 7, 8
+
+# messages of the reference for the device-side failure codes (dp_utils.py:124,167,243)
+DEVICE_ERRORS = {
+    SVX_ERR_TRACEBACK: "traceback bug",
+    SVX_ERR_BP: "got unknown value",
+    SVX_ERR_EXTEND: "asked to extend alignments but already bigger than requested",
+    SVX_ERR_PATH: "search path is not a unit-step lattice path",
+}
+
+c_int, c_i64, c_f32, c_f64, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
+
+
+class AlignParams(ctypes.Structure):
+    _fields_ = [
+        ("dtype", ctypes.c_int32),
+        ("d", ctypes.c_int32),
+        ("n_types", ctypes.c_int32),
+        ("types", ctypes.c_int32 * (2 * SVX_MAX_TYPES)),
+        ("width_over2", ctypes.c_int32),
+        ("max_size_full_dp", ctypes.c_int32),
+        ("costs_sample_size", ctypes.c_int32),
+        ("num_samps_for_norm", ctypes.c_int32),
+        ("del_percentile_frac", ctypes.c_double),
+    ]
+
+
+class Pair(ctypes.Structure):
+    _fields_ = [
+        ("vecs0", c_vp), ("vecs1", c_vp),
+        ("n", ctypes.c_int32), ("m", ctypes.c_int32), ("k0", ctypes.c_int32), ("k1", ctypes.c_int32),
+        ("norm_idx", c_vp), ("knob_idx", c_vp),
+        ("norms0", c_vp), ("norms1", c_vp),
+        ("align", c_vp), ("scores", c_vp), ("info", c_vp), ("del_pen", c_vp),
+    ]
+
+
+_SIGS = {
+    "svx_create": (c_int, [c_int, ctypes.POINTER(c_vp)]),
+    "svx_destroy": (c_int, [c_vp]),
+    "svx_set_stream": (c_int, [c_vp, c_vp]),
+    "svx_synchronize": (c_int, [c_vp]),
+    "svx_last_error": (ctypes.c_char_p, [c_vp]),
+    "svx_version": (ctypes.c_char_p, []),
+    "svx_scratch_bytes": (c_i64, [c_vp]),
+    "svx_dense_costs": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
+    "svx_dense_dp": (c_int, [c_vp, c_vp, c_int, c_int, c_f32, c_vp, c_vp]),
+    "svx_score_path": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp]),
+    "svx_sparse_costs": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int,
+                                 ctypes.POINTER(ctypes.c_int32), c_int, c_int, c_vp, c_vp]),
+    "svx_sparse_dp": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, ctypes.POINTER(ctypes.c_int32), c_int, c_f64, c_int, c_int,
+                              c_vp, c_vp, c_vp, c_vp]),
+    "svx_make_norm1": (c_int, [c_vp, c_vp, c_i64, c_int]),
+    "svx_downsample": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "svx_compute_norms": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
+    "svx_del_penalty": (c_int, [c_vp, c_vp, c_i64, c_f64, c_vp]),
+    "svx_dense_traceback": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    "svx_sparse_traceback": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "svx_search_path": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "svx_num_levels": (c_int, [c_int, c_int, c_int]),
+    "svx_knob_count": (c_i64, [c_int, c_int, c_int]),
+    "svx_align_batch": (c_int, [c_vp, ctypes.POINTER(AlignParams), ctypes.POINTER(Pair), c_int]),
+    "svx_set_profiling": (c_int, [c_vp, c_int]),
+    "svx_stage_ms": (c_f64, [c_vp, ctypes.c_char_p]),
+    "svx_stage_launches": (c_int, [c_vp, ctypes.c_char_p]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load libsvx.so (built by __graft_entry__.build() / `make -C speech-vecalign_amd/csrc`)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    "libsvx.so not found at %s: build it with `make -C speech-vecalign_amd/csrc` "
+                    "(there is no CPU fallback)" % LIB_PATH)
+            L = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGS.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+    return _lib
+
+
+class SvxError(Exception):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class Context:
+    """One svx_ctx per (process, device)."""
+
+    def __init__(self, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("svx needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.lib = load()
+        self.device = int(device)
+        h = c_vp()
+        rc = self.lib.svx_create(self.device, ctypes.byref(h))
+        if rc != 0:
+            raise SvxError(rc, self.lib.svx_last_error(None).decode())
+        self.h = h
+        self.torch = torch
+        self.tdev = torch.device("cuda", self.device)
+
+    def use_current_stream(self):
+        self.lib.svx_set_stream(self.h, c_vp(self.torch.cuda.current_stream(self.tdev).cuda_stream))
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self.lib.svx_last_error(self.h).decode()
+            if rc == SVX_ERR_OVERLAPS:
+                raise Exception(msg)  # the reference raises a plain Exception with this text
+            raise SvxError(rc, msg)
+
+    def sync(self):
+        self.check(self.lib.svx_synchronize(self.h))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.svx_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+_ctxs = {}
+
+
+def context(device=0):
+    device = int(device)
+    if device not in _ctxs:
+        _ctxs[device] = Context(device)
+    c = _ctxs[device]
+    c.use_current_stream()
+    return c

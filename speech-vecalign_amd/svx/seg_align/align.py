@@ -1,0 +1,162 @@
+"""Segment-alignment driver: the reference's `python -m svecalign.seg_align.align` on MI355X.
+
+Same positional arguments, flags, directory conventions and output format as
+svecalign/seg_align/align.py (parse_args :13-96, validate_inputs :117-179, main :182-230):
+
+    python -m svx.seg_align.align METADATA OUT_DIR --src_lang en --tgt_lang de \
+        --seg_dir D --concat_dir D --embed_dir D [--is_stopes_embed] [--fp16_embed] [-a 6] ...
+
+Additive flags only: --batch_size (document pairs aligned per device pass; the reference loops one
+pair at a time), --seed (per-pair sampling streams derived from (seed, pair index): results do not
+depend on batch size or shard count; without it the global numpy stream is consumed pair after
+pair exactly like the reference), --skip_existing, --rank/--n_shard (default from torchrun's
+RANK/WORLD_SIZE: one process per GPU, pairs split by cost, no collective needed).
+"""
+import argparse
+import dataclasses
+import logging
+import os
+from pathlib import Path
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+
+from ..utils.file_utils import check_exist, read_metadata
+from ..utils.log_utils import my_tqdm
+from ..utils.mp_utils import balanced_shards
+from ..vecalign.vecalign import load_document, print_alignments, resolve_search_params
+
+logger = logging.getLogger(__name__)
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("metadata", type=str, help="the meta file that each line contains paired audio paths")
+    p.add_argument("out_dir", type=str, help="dir to save alignments.")
+    p.add_argument("--src_lang", type=str, required=True)
+    p.add_argument("--tgt_lang", type=str, required=True)
+    p.add_argument("--seg_dir", type=str, required=True, help="the dir for raw segments.")
+    p.add_argument("--concat_dir", type=str, required=True, help="the dir for concatenated segments.")
+    p.add_argument("--embed_dir", type=str, required=True, help="Dir to embedding files.")
+    p.add_argument("--is_stopes_embed", action="store_true", default=False, help="embeddings were dumped by stopes (SpeechLASER).")
+    p.add_argument("--fp16_embed", action="store_true", default=False, help="embeddings are raw fp16 (SONAR numpy dumps)")
+    p.add_argument('-a', '--alignment_max_size', dest="alignment_max_size", type=int, default=6,
+                   help='Searches for alignments up to size N-M, where N+M <= this value.')
+    p.add_argument('--search_buffer_size', type=int, default=5, help='Width (one side) of search buffer.')
+    p.add_argument('-d', '--del_percentile_frac', dest="del_percentile_frac", type=float, default=0.2,
+                   help='Deletion penalty percentile (fraction) of the cost distribution.')
+    p.add_argument('--max_size_full_dp', type=int, default=300, help='Largest N for full N^2 dynamic programming.')
+    p.add_argument('--costs_sample_size', type=int, default=20000, help='Samples for the cost distribution.')
+    p.add_argument('--num_samps_for_norm', type=int, default=100, help='Samples for normalizing embeddings')
+    p.add_argument("--ign_indices_dir", type=str, default=None,
+                   help="if provided, then some segments will be ignored when loading embeddings.")
+    # additive
+    p.add_argument("--batch_size", type=int, default=32, help="document pairs per device pass")
+    p.add_argument("--seed", type=int, default=None, help="derive one sampling stream per pair from (seed, pair index)")
+    p.add_argument("--skip_existing", action="store_true", default=False, help="do not recompute existing outputs")
+    p.add_argument("--rank", type=int, default=int(os.environ.get("RANK", 0)))
+    p.add_argument("--n_shard", type=int, default=int(os.environ.get("WORLD_SIZE", 1)))
+    return p.parse_args(argv)
+
+
+@dataclasses.dataclass
+class VecalignData:
+    src_seg_path: str
+    tgt_seg_path: str
+    src_concat_path: str
+    tgt_concat_path: str
+    src_embed_path: str
+    tgt_embed_path: str
+    output_path: str
+    src_ignore_indices: Optional[Union[str, Path]] = None
+    tgt_ignore_indices: Optional[Union[str, Path]] = None
+    index: int = 0  # position in the validated list (seeds derive from it)
+
+
+def validate_inputs(audio_pairs: List[Tuple[str, str]], src_seg_dir: Path, tgt_seg_dir: Path, src_concat_dir: Path,
+                    tgt_concat_dir: Path, src_embed_dir: Path, tgt_embed_dir: Path, out_dir: Path,
+                    ign_indices_dir: Optional[Path] = None) -> List[VecalignData]:
+    """Resolve the per-pair file set; pairs with a missing file are dropped (align.py:117-179)."""
+    res = []
+    for src_audio, tgt_audio in audio_pairs:
+        s, t = Path(src_audio), Path(tgt_audio)
+        found = {}
+        for kind, sdir, tdir, suffix in (("seg", src_seg_dir, tgt_seg_dir, ".txt"),
+                                         ("concat", src_concat_dir, tgt_concat_dir, ".txt"),
+                                         ("embed", src_embed_dir, tgt_embed_dir, ".embed")):
+            sp, tp = (sdir / s.name).with_suffix(suffix), (tdir / t.name).with_suffix(suffix)
+            if not check_exist(sp) or not check_exist(tp):
+                found = None
+                break
+            found[kind] = (sp.as_posix(), tp.as_posix())
+        if found is None:
+            continue
+        src_ign = tgt_ign = None
+        if ign_indices_dir is not None:
+            src_ign = ign_indices_dir / f"{s.stem}-{t.stem}.src.txt"
+            tgt_ign = ign_indices_dir / f"{s.stem}-{t.stem}.tgt.txt"
+            src_ign = src_ign if check_exist(src_ign) else None
+            tgt_ign = tgt_ign if check_exist(tgt_ign) else None
+        res.append(VecalignData(found["seg"][0], found["seg"][1], found["concat"][0], found["concat"][1],
+                                found["embed"][0], found["embed"][1], (out_dir / f"{s.stem}-{t.stem}.txt").as_posix(),
+                                src_ign, tgt_ign, index=len(res)))
+    return res
+
+
+def pair_rng(seed: Optional[int], index: int):
+    """Independent legacy RandomState per pair, a pure function of (seed, pair index)."""
+    if seed is None:
+        return None
+    return np.random.RandomState(np.random.SeedSequence([seed, index]).generate_state(4))
+
+
+def align_pairs(pairs: List[VecalignData], args, batch_size: int):
+    from ..vecalign.dp_utils import align_batch
+    types, src_k, tgt_k, width_over2 = resolve_search_params(args.alignment_max_size, None, args.search_buffer_size)
+    todo = [p for p in pairs if not (args.skip_existing and Path(p.output_path).exists())]
+    for b0 in my_tqdm(range(0, len(todo), batch_size)):
+        chunk = todo[b0:b0 + batch_size]
+        docs = []
+        for p in chunk:
+            _, sv = load_document(p.src_seg_path, [p.src_concat_path, p.src_embed_path], args.is_stopes_embed,
+                                  args.fp16_embed, src_k, p.src_ignore_indices, True)
+            _, tv = load_document(p.tgt_seg_path, [p.tgt_concat_path, p.tgt_embed_path], args.is_stopes_embed,
+                                  args.fp16_embed, tgt_k, p.tgt_ignore_indices, True)
+            docs.append((sv, tv))
+        rngs = None if args.seed is None else [pair_rng(args.seed, p.index) for p in chunk]
+        results = align_batch(docs, types, args.del_percentile_frac, width_over2, args.max_size_full_dp,
+                              args.costs_sample_size, args.num_samps_for_norm, rngs=rngs)
+        for p, (alignments, scores, _) in zip(chunk, results):
+            tmp = p.output_path + ".tmp"
+            with open(tmp, "w") as fp:  # write-then-rename, the repo's crash-safety idiom
+                print_alignments(alignments, scores=scores, ofile=fp)
+            Path(tmp).replace(p.output_path)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    logger.info(args)
+    src_lang, tgt_lang = args.src_lang, args.tgt_lang
+    out_dir = Path(args.out_dir) / f"{src_lang}-{tgt_lang}"
+    out_dir.mkdir(parents=True, exist_ok=True)
+    ign = None
+    if args.ign_indices_dir is not None:
+        ign = Path(args.ign_indices_dir) / f"{src_lang}-{tgt_lang}"
+        logger.info(f"Will ignore segments indicated by {ign}")
+    valid = validate_inputs(read_metadata(args.metadata),
+                            Path(args.seg_dir) / src_lang, Path(args.seg_dir) / tgt_lang,
+                            Path(args.concat_dir) / src_lang, Path(args.concat_dir) / tgt_lang,
+                            Path(args.embed_dir) / src_lang, Path(args.embed_dir) / tgt_lang, out_dir, ign)
+    if args.n_shard > 1:
+        # one process per GPU; document pairs are independent, so shards never communicate
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", args.rank)) % max(1, torch.cuda.device_count()))
+        costs = [os.path.getsize(p.src_embed_path) + os.path.getsize(p.tgt_embed_path) for p in valid]
+        valid = [valid[i] for i in balanced_shards(costs, args.n_shard)[args.rank]]
+        logger.info(f"rank {args.rank} of {args.n_shard}: {len(valid)} pairs")
+    align_pairs(valid, args, max(1, args.batch_size))
+
+
+if __name__ == '__main__':
+    main()
