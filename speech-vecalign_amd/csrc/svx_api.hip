@@ -376,8 +376,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
     const int B = 2 * W;
     int mx = 0, my = 0;
     for (int t = 0; t < tfinal.n; t++) { if (tfinal.x[t] > mx) mx = tfinal.x[t]; if (tfinal.y[t] > my) my = tfinal.y[t]; }
-    const size_t esz = dtype == SVX_F32 ? 4 : 2;
-    (void)esz;
+    const bool packable = mx <= 15 && my <= 15;  // back-pointers fit 4 bits each
 
     // ---- plan: level sizes, scratch layout, launch extents
     std::vector<SvxPairDev>& host = cx->host;
@@ -465,8 +464,12 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
                 OFF(Lv.costs, (size_t)(T > 0 ? T : 1) * cap * B * sizeof(float));
                 OFF(Lv.boff, (size_t)cap * sizeof(int));
                 OFF(Lv.csum, (size_t)(cap + 2) * B * sizeof(double));
-                OFF(Lv.xp, (size_t)(cap + 2) * B * sizeof(int));
-                OFF(Lv.yp, (size_t)(cap + 2) * B * sizeof(int));
+                if (packable) {
+                    OFF(Lv.bpk, (size_t)(cap + 2) * B);
+                } else {
+                    OFF(Lv.xp, (size_t)(cap + 2) * B * sizeof(int));
+                    OFF(Lv.yp, (size_t)(cap + 2) * B * sizeof(int));
+                }
                 OFF(Lv.boff_out, (size_t)(cap + 2) * sizeof(int));
             }
             if (l == 0) {
@@ -506,7 +509,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             }
             patch(Lv.kscore);
             if (!in.del_pen) patch(Lv.pen);
-            patch(Lv.path); patch(Lv.path_len); patch(Lv.costs); patch(Lv.boff); patch(Lv.csum); patch(Lv.xp); patch(Lv.yp);
+            patch(Lv.path); patch(Lv.path_len); patch(Lv.costs); patch(Lv.boff); patch(Lv.csum); patch(Lv.xp); patch(Lv.yp); patch(Lv.bpk);
             patch(Lv.boff_out);
             if (l > 0) { patch(Lv.align); patch(Lv.scores); patch(Lv.n_align); }
         }
@@ -562,7 +565,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             const SvxTypes& ty = depth == 0 ? tfinal : t11;
             {
                 StageScope sc(ctx, S_PATH);
-                if ((rc = svxl_search_path_batch(ctx, dpairs, n_pairs, depth))) return rc;
+                if ((rc = svxl_search_path_batch(ctx, dpairs, n_pairs, depth, max_A[depth]))) return rc;
             }
             {
                 StageScope sc(ctx, depth == 0 ? S_BAND_COSTS0 : S_BAND_COSTSN);
@@ -574,7 +577,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             }
             {
                 StageScope sc(ctx, S_TRACEBACK);
-                if ((rc = svxl_sparse_traceback_batch(ctx, dpairs, n_pairs, depth, B))) return rc;
+                if ((rc = svxl_sparse_traceback_batch(ctx, dpairs, n_pairs, depth, B, max_A[depth], packable ? 1 : 0))) return rc;
             }
         }
     }

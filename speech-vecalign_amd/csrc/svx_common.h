@@ -95,11 +95,12 @@ struct SvxLevel {
     double* pen;       // deletion penalty of this level
     int* path;         // [path_cap][2]
     int* path_len;
-    float* costs;      // [T][A][B]
+    float* costs;      // [A][T][B] (fused pipeline layout: one diagonal's costs are contiguous)
     int* boff;         // [A]
     double* csum;      // [A+2][B]
-    int* xp;
+    int* xp;           // int32 back-pointers (only when the types do not pack into 4 bits)
     int* yp;
+    unsigned char* bpk;  // packed back-pointers [A+2][B]: xp << 4 | yp, 0xFF = unreachable
     int* boff_out;     // [A+2]
     int* align;        // [n0+n1+2][4]
     int* n_align;
@@ -179,9 +180,9 @@ int svxl_sparse_dp(svx_ctx*, const float* costs, const int* boff_in, int A, int 
 int svxl_sparse_dp_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, const SvxTypes& types, int B);
 int svxl_sparse_traceback(svx_ctx*, const double* csum, const int* xp, const int* yp, const int* boff, int a_out,
                           int B, int xs, int ys, int* align, double* scores, int* count);
-int svxl_sparse_traceback_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int B);
+int svxl_sparse_traceback_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int B, int max_A, int packed);
 int svxl_search_path(svx_ctx*, const int* align, const int* n_align, int upsample, int size0, int size1, int* path,
                      int cap, int* path_len);
-int svxl_search_path_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth);
+int svxl_search_path_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int max_rows);
 int svxl_del_penalty(svx_ctx*, const float* scores, int64_t n, double frac, double* out);
 int svxl_del_penalty_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_levels, double frac);

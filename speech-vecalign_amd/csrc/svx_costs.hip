@@ -81,6 +81,7 @@ __device__ __forceinline__ void stage_slab(char* slab, const char* const* rowptr
 }
 
 __device__ __forceinline__ float cost_formula(float sumx, int p, int q, float n0, float n1) {
+#pragma clang fp contract(off)
     // dp_core.pyx:259-260, evaluated in double like the generated C, stored to float
     return (float)((((2.0 * (double)p) * (double)q) * (1.0 - (double)sumx)) / ((1e-6 + (double)n0) + (double)n1));
 }
@@ -262,9 +263,10 @@ struct BandArgs {
     const float* nrm1;
     const int* path;  // [A][2]
     int A, W;
-    float* costs;  // [T][A][2W]
+    float* costs;  // [T][A][2W], or [A][T][2W] when atb != 0
     int* boff;     // [A]
     int* status;   // set to SVX_ERR_PATH when the path is not a unit-step lattice path
+    int atb;
 };
 
 __host__ __device__ inline size_t band_smem_bytes(int kx, int ky) {
@@ -400,9 +402,22 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
         const int ntp = (ty.n - pass * TPP) < TPP ? (ty.n - pass * TPP) : TPP;
         const int per = TAe * TBe;
         for (int idx = tid; idx < ntp * per; idx += BC_THREADS) {
-            const int tl = idx / per, rem = idx % per;
-            const int ai = rem / TBe, bi = rem % TBe;
-            g.costs[((size_t)(pass * TPP + tl) * g.A + (a0 + ai)) * B + (b0 + bi)] = Fs[((size_t)tl * TA + ai) * TB + bi];
+            // atb: a-major order so that consecutive threads write consecutive addresses
+            int tl, ai, bi;
+            if (g.atb) {
+                ai = idx / (ntp * TBe);
+                const int rem = idx % (ntp * TBe);
+                tl = rem / TBe;
+                bi = rem % TBe;
+            } else {
+                tl = idx / per;
+                const int rem = idx % per;
+                ai = rem / TBe;
+                bi = rem % TBe;
+            }
+            const int t = pass * TPP + tl;
+            const size_t o = g.atb ? ((size_t)(a0 + ai) * ty.n + t) * B + (b0 + bi) : ((size_t)t * g.A + (a0 + ai)) * B + (b0 + bi);
+            g.costs[o] = Fs[((size_t)tl * TA + ai) * TB + bi];
         }
     }
 }
@@ -439,6 +454,7 @@ __global__ __launch_bounds__(BC_THREADS) void k_band_costs_batch(const SvxPairDe
     g.costs = Lv.costs;
     g.boff = Lv.boff;
     g.status = P.status;
+    g.atb = 1;
     band_block<E>(g, ty, kx, ky, chunk_a, blockIdx.x % nchunk_b, smem);
 }
 
@@ -565,7 +581,7 @@ int svxl_band_costs(svx_ctx* ctx, const void* v0, int k0, int n, const void* v1,
     if (smem > 160 * 1024) return svx_fail(ctx, SVX_ERR_ARG, "band costs: %d+%d overlap layers need %zu bytes of LDS (>160 KiB)", kx, ky, smem);
     const int B = 2 * W;
     const int nca = (A + TA - 1) / TA, ncb = (B + TB - 1) / TB;
-    BandArgs g{v0, v1, n, m, d, inv0, inv1, nrm0, nrm1, path, A, W, costs, boff, status};
+    BandArgs g{v0, v1, n, m, d, inv0, inv1, nrm0, nrm1, path, A, W, costs, boff, status, 0};
     dim3 grid((unsigned)(nca * ncb));
 #define LAUNCH(E)                                                                                                   \
     do {                                                                                                            \

@@ -121,22 +121,36 @@ __global__ __launch_bounds__(256) void k_dense_stage_batch(const SvxPairDev* __r
 
 // ------------------------------------------------------------------------------ band DP
 struct SparseDpArgs {
-    const float* costs;  // [T][A][B]
+    const float* costs;  // [T][A][B] (atb == 0, the reference layout) or [A][T][B] (atb != 0, fused pipeline)
     const int* boff_in;  // [A]
     int A, B;
     double pen;
-    int xs, ys;    // x_in_size, y_in_size
-    double* csum;  // [A+2][B]
-    int* xp;
+    int xs, ys;          // x_in_size, y_in_size
+    double* csum;        // [A+2][B]
+    int* xp;             // [A+2][B] or null when bpk is given
     int* yp;
-    int* boff_out;  // [A+2]
+    unsigned char* bpk;  // optional packed back-pointers: xp << 4 | yp, 0xFF = unreachable (-42)
+    int* boff_out;       // [A+2]
+    int atb;
 };
 
+__device__ __forceinline__ size_t cost_index(const SparseDpArgs& g, int T, int t, int a, int b) {
+    return g.atb ? ((size_t)a * T + t) * g.B + b : ((size_t)t * g.A + a) * g.B + b;
+}
+__device__ __forceinline__ void store_node(const SparseDpArgs& g, size_t o, double v, int bx, int by) {
+    g.csum[o] = v;
+    if (g.xp) { g.xp[o] = bx; g.yp[o] = by; }
+    if (g.bpk) g.bpk[o] = bx < 0 ? (unsigned char)0xFF : (unsigned char)((bx << 4) | by);
+}
+
+// Generic kernel: any band width, cells strided over the workgroup, costs read straight from
+// global memory.  RING: the last maxstep+1 diagonals of csum live in LDS, else they are re-read
+// from the csum output array.
 template <bool RING>
 __device__ void sparse_dp_block(const SparseDpArgs& g, const SvxTypes& ty, double* ring) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int A = g.A, B = g.B, Aout = g.A + 2;
-    const int NTt = ty.n + 2;
+    const int T = ty.n, NTt = ty.n + 2;
     const int RD = ty.maxstep + 1;
     const int x_out = g.xs + 1, y_out = g.ys + 1;
     for (int a = tid; a < Aout; a += nt) g.boff_out[a] = a < 2 ? g.boff_in[0] : g.boff_in[a - 2] + 1;
@@ -169,8 +183,7 @@ __device__ void sparse_dp_block(const SparseDpArgs& g, const SvxTypes& ty, doubl
                                     const int ap = xpv + ypv;  // 0 <= ap < a
                                     const int bpv = ypv - g.boff_out[ap];
                                     if (0 <= bpv && bpv < B) {
-                                        const double ac_cost =
-                                            (xo == 0 || yo == 0) ? g.pen : (double)g.costs[((size_t)t * A + ac) * B + bc];
+                                        const double ac_cost = (t >= T) ? g.pen : (double)g.costs[cost_index(g, T, t, ac, bc)];
                                         const double prev = RING ? ring[(size_t)(ap % RD) * B + bpv] : g.csum[(size_t)ap * B + bpv];
                                         const double tot = prev + ac_cost;
                                         if (tot < best) { best = tot; bx = xo; by = yo; }
@@ -182,9 +195,159 @@ __device__ void sparse_dp_block(const SparseDpArgs& g, const SvxTypes& ty, doubl
                 }
             }
             if (RING) ring[(size_t)(a % RD) * B + b] = best;
-            g.csum[o] = best;
-            g.xp[o] = bx;
-            g.yp[o] = by;
+            store_node(g, o, best, bx, by);
+        }
+        __syncthreads();
+    }
+}
+
+// Fast kernel for narrow bands (B <= 64): wave 0 sweeps the diagonals touching only LDS -- the
+// csum ring, a ring of b_offset_out and a double-buffered chunk of CH diagonals of costs -- while
+// waves 1-3 stage the next chunk from HBM, so no global load sits on the serial chain.
+constexpr int DPF_THREADS = 256;
+
+__host__ __device__ inline size_t dpf_smem_bytes(int T, int B, int RD, int CH) {
+    return (size_t)RD * B * sizeof(double)                      // csum ring
+           + (size_t)(SVX_MAX_TYPES + 2) * sizeof(int)          // packed transitions
+           + 2 * (size_t)CH * sizeof(int)                       // b_offset_out of the chunk
+           + 2 * (size_t)CH * (T + 2) * sizeof(int)             // lane shift per (diagonal, transition)
+           + 2 * (size_t)CH * (T > 0 ? T : 1) * B * sizeof(float);  // costs
+}
+
+// Stage chunk c (node diagonals a0 .. a0+CH-1) into buffer c&1: b_offset_out, the lane shift of every
+// transition and the cost rows a-2.  Everything is derived from global memory (b_offset_in is tiny
+// and cached), so the staging waves need no hand-off between themselves.
+__device__ __forceinline__ void dpf_stage(const SparseDpArgs& g, const int* tpk, int T, int CH, int c, int* bo_buf, int* sh_buf,
+                                          float* cbuf, int tsub, int nsub) {
+    const int A = g.A, B = g.B, Aout = A + 2, NTt = T + 2;
+    const int a0 = c * CH;
+    int* bo = bo_buf + (size_t)(c & 1) * CH;
+    int* sh = sh_buf + (size_t)(c & 1) * CH * NTt;
+    for (int i = tsub; i < CH; i += nsub) {
+        const int a = a0 + i;
+        bo[i] = (a < Aout) ? (a < 2 ? g.boff_in[0] : g.boff_in[a - 2] + 1) : 0;
+    }
+    for (int idx = tsub; idx < CH * NTt; idx += nsub) {
+        const int i = idx / NTt, t = idx - i * NTt;
+        const int a = a0 + i;
+        const int pk = tpk[t];
+        const int yo = (pk >> 8) & 255, st = pk >> 16;
+        int v = 1 << 20;  // no predecessor diagonal: pushes the lane index out of the band
+        if (a < Aout && a - st >= 0) {
+            const int boa = a < 2 ? g.boff_in[0] : g.boff_in[a - 2] + 1;
+            const int ap = a - st;
+            const int bop = ap < 2 ? g.boff_in[0] : g.boff_in[ap - 2] + 1;
+            v = boa - yo - bop;  // predecessor cell = lane + v on diagonal a - st
+        }
+        sh[idx] = v;
+    }
+    const int TB = T * B;
+    const int total = CH * TB;
+    float* dst = cbuf + (size_t)(c & 1) * total;
+    if (g.atb) {
+        // [A][T][B]: the chunk is one contiguous run of cost rows a0-2 .. a0-2+CH
+        const long long first = (long long)(a0 - 2) * TB;
+        const long long limit = (long long)A * TB;
+        for (int idx = tsub; idx < total; idx += nsub) {
+            const long long o = first + idx;
+            dst[idx] = (o >= 0 && o < limit) ? g.costs[o] : 0.f;
+        }
+    } else {
+        for (int idx = tsub; idx < total; idx += nsub) {
+            const int i = idx / TB, rem = idx - i * TB;
+            const int ac = a0 + i - 2;  // cost row of node diagonal a0 + i
+            float v = 0.f;
+            if (ac >= 0 && ac < A) {
+                const int t = rem / B, b = rem - t * B;
+                v = g.costs[cost_index(g, T, t, ac, b)];
+            }
+            dst[idx] = v;
+        }
+    }
+}
+
+// G lane groups of LB = 64/G lanes share one diagonal: lane = grp*LB + b, group grp relaxes the
+// transitions t = grp, grp+G, ...; the per-group winners are merged by (total, t) so that the
+// reference's "first strictly smaller candidate wins" order is preserved exactly.
+__device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int A = g.A, B = g.B, Aout = A + 2, T = ty.n, NTt = ty.n + 2, RD = ty.maxstep + 1;
+    const int G = B <= 16 ? 4 : (B <= 32 ? 2 : 1);
+    const int LB = 64 / G;
+    const int b = lane & (LB - 1), grp = lane / LB;
+    double* ring = reinterpret_cast<double*>(smem);
+    int* tpk = reinterpret_cast<int*>(ring + (size_t)RD * B);
+    int* bo_buf = tpk + (SVX_MAX_TYPES + 2);
+    int* sh_buf = bo_buf + 2 * CH;
+    float* cbuf = reinterpret_cast<float*>(sh_buf + 2 * (size_t)CH * NTt);
+    const int TB = T * B;
+    for (int t = tid; t < NTt; t += DPF_THREADS) tpk[t] = (int)ty.x[t] | ((int)ty.y[t] << 8) | (((int)ty.x[t] + (int)ty.y[t]) << 16);
+    for (int a = tid; a < Aout; a += DPF_THREADS) g.boff_out[a] = a < 2 ? g.boff_in[0] : g.boff_in[a - 2] + 1;
+    __syncthreads();
+    dpf_stage(g, tpk, T, CH, 0, bo_buf, sh_buf, cbuf, tid, DPF_THREADS);
+    __syncthreads();
+    const int nchunks = (Aout + CH - 1) / CH;
+    const double inf = __builtin_inf();
+    const double pen = g.pen;
+    int slot = 0;  // a % RD, maintained incrementally (wave 0 only)
+    for (int c = 0; c < nchunks; c++) {
+        const int a0 = c * CH;
+        if (wave >= 1) {
+            if (c + 1 < nchunks) dpf_stage(g, tpk, T, CH, c + 1, bo_buf, sh_buf, cbuf, tid - 64, DPF_THREADS - 64);
+        } else {
+            const float* cb = cbuf + (size_t)(c & 1) * CH * TB;
+            const int* bo = bo_buf + (size_t)(c & 1) * CH;
+            const int* sh = sh_buf + (size_t)(c & 1) * CH * NTt;
+            const int a_end = (a0 + CH) < Aout ? (a0 + CH) : Aout;
+            for (int a = a0; a < a_end; a++) {
+                const int i = a - a0;
+                const bool active = b < B;
+                const int yy = b + bo[i];
+                const int xx = a - yy;
+                double best = inf;
+                int bt = 1 << 20;
+                // general node: cost cell (a-2, b) exists (b_offset_out[a] = b_offset_in[a-2] + 1, so bc == b)
+                const bool general = active && 1 <= xx && xx <= g.xs && 1 <= yy && yy <= g.ys && a - 2 < A;
+                if (general) {
+                    const float* crow = cb + (size_t)i * TB + b;
+                    const int* shr = sh + (size_t)i * NTt;
+                    for (int t = grp; t < NTt; t += G) {
+                        const int pk = tpk[t];
+                        const int xo = pk & 255, yo = (pk >> 8) & 255, st = pk >> 16;
+                        const int bpv = b + shr[t];
+                        const bool ok = xo <= xx && yo <= yy && 0 <= bpv && bpv < B;
+                        int ps = slot - st;
+                        ps = ps < 0 ? ps + RD : ps;
+                        const double prev = ring[(size_t)ps * B + (ok ? bpv : 0)];
+                        const double ac_cost = (t >= T) ? pen : (double)crow[t * B];
+                        const double tot = prev + ac_cost;
+                        if (ok && tot < best) { best = tot; bt = t; }
+                    }
+                }
+                // merge the groups: smaller total wins, equal totals -> smaller transition index
+                for (int m = LB; m < 64; m <<= 1) {
+                    const double ob = __shfl_xor(best, m, 64);
+                    const int ot = __shfl_xor(bt, m, 64);
+                    if (ob < best || (ob == best && ot < bt)) { best = ob; bt = ot; }
+                }
+                if (active && grp == 0) {
+                    int bx, by;
+                    if (xx == 0 && 0 <= yy && yy <= g.ys) {
+                        best = pen * (double)yy; bx = 0; by = 1;
+                    } else if (yy == 0 && 0 <= xx && xx <= g.xs) {
+                        best = pen * (double)xx; bx = 1; by = 0;
+                    } else if (bt < NTt) {
+                        const int pk = tpk[bt];
+                        bx = pk & 255; by = (pk >> 8) & 255;
+                    } else {
+                        best = inf; bx = -42; by = -42;
+                    }
+                    ring[(size_t)slot * B + b] = best;
+                    store_node(g, (size_t)a * B + b, best, bx, by);
+                }
+                slot = (slot + 1 == RD) ? 0 : slot + 1;
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         __syncthreads();
     }
@@ -196,55 +359,125 @@ __global__ __launch_bounds__(1024) void k_sparse_dp(SparseDpArgs g, SvxTypes ty)
     sparse_dp_block<RING>(g, ty, reinterpret_cast<double*>(smem));
 }
 
+__global__ __launch_bounds__(DPF_THREADS) void k_sparse_dp_fast(SparseDpArgs g, SvxTypes ty, int CH) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    sparse_dp_fast(g, ty, CH, smem);
+}
+
+__device__ __forceinline__ bool batch_dp_args(const SvxPairDev& P, int depth, int B, SparseDpArgs* g) {
+    if (depth > P.L || (depth == P.L && P.L > 0)) return false;
+    if (*P.status != 0) return false;
+    const SvxLevel& Lv = P.lev[depth];
+    g->A = *Lv.path_len;
+    if (g->A <= 0) return false;
+    g->costs = Lv.costs;
+    g->boff_in = Lv.boff;
+    g->B = B;
+    g->pen = *Lv.pen;
+    g->xs = Lv.n[0];
+    g->ys = Lv.n[1];
+    g->csum = Lv.csum;
+    g->xp = Lv.xp;
+    g->yp = Lv.yp;
+    g->bpk = Lv.bpk;
+    g->boff_out = Lv.boff_out;
+    g->atb = 1;
+    return true;
+}
+
 template <bool RING>
 __global__ __launch_bounds__(1024) void k_sparse_dp_batch(const SvxPairDev* __restrict__ pairs, int depth, SvxTypes ty, int B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const SvxPairDev& P = pairs[blockIdx.x];
-    if (depth > P.L || (depth == P.L && P.L > 0)) return;
-    if (*P.status != 0) return;
-    const SvxLevel& Lv = P.lev[depth];
     SparseDpArgs g;
-    g.A = *Lv.path_len;
-    if (g.A <= 0) return;
-    g.costs = Lv.costs;
-    g.boff_in = Lv.boff;
-    g.B = B;
-    g.pen = *Lv.pen;
-    g.xs = Lv.n[0];
-    g.ys = Lv.n[1];
-    g.csum = Lv.csum;
-    g.xp = Lv.xp;
-    g.yp = Lv.yp;
-    g.boff_out = Lv.boff_out;
+    if (!batch_dp_args(pairs[blockIdx.x], depth, B, &g)) return;
     sparse_dp_block<RING>(g, ty, reinterpret_cast<double*>(smem));
 }
 
+__global__ __launch_bounds__(DPF_THREADS) void k_sparse_dp_fast_batch(const SvxPairDev* __restrict__ pairs, int depth,
+                                                                       SvxTypes ty, int B, int CH) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SparseDpArgs g;
+    if (!batch_dp_args(pairs[blockIdx.x], depth, B, &g)) return;
+    sparse_dp_fast(g, ty, CH, smem);
+}
+
 // ------------------------------------------------------------------------------ band traceback
-// Thread 0 walks the back-pointers from (xs,ys) to (0,0) writing rows and cumulative costs from
-// the back of the buffers; then the whole workgroup moves them to the front in document order
-// and turns cumulative costs into scores (process_scores).  cap = xs + ys + 2 rows / doubles.
-__device__ void sparse_traceback_block(const double* csum, const int* xp, const int* yp, const int* boff, int Aout, int B,
-                                       int xs, int ys, int* align, double* scores, int* count, int* status) {
+// Thread 0 walks the back-pointers from (xs,ys) to (0,0) and writes the alignment rows from the
+// back of the buffer; when they fit, b_offset_out and the packed back-pointers are first copied
+// into LDS so that the pointer chase never leaves the CU.  Then the whole workgroup moves the rows
+// to the front in document order and computes the scores from csum (process_scores).
+// cap = xs + ys + 2 rows / doubles.
+struct TbArgs {
+    const double* csum;
+    const int* xp;             // int32 back-pointers, or null when bpk is given
+    const int* yp;
+    const unsigned char* bpk;  // packed back-pointers or null
+    const int* boff;           // b_offset_out [Aout]
+    int Aout, B, xs, ys;
+    int* align;
+    double* scores;
+    int* count;
+    int* status;
+    int use_lds;               // LDS holds boff [Aout] ints, then bp [Aout*B]: bytes (from bpk) or 16-bit (from xp/yp)
+};
+
+__host__ __device__ inline size_t tb_smem_bytes(int Aout, int B, bool wide) {
+    return (size_t)Aout * sizeof(int) + (size_t)Aout * B * (wide ? 2 : 1);
+}
+
+__device__ void sparse_traceback_block(const TbArgs& g, char* smem) {
     __shared__ int sh_n;
-    const int cap = xs + ys + 2;
+    const int cap = g.xs + g.ys + 2;
+    const int Aout = g.Aout, B = g.B;
+    int* lbo = reinterpret_cast<int*>(smem);
+    unsigned char* lbp = reinterpret_cast<unsigned char*>(smem) + (size_t)Aout * sizeof(int);
+    unsigned short* lbw = reinterpret_cast<unsigned short*>(lbp);
+    if (g.use_lds) {
+        for (int i = threadIdx.x; i < Aout; i += blockDim.x) lbo[i] = g.boff[i];
+        const size_t nb = (size_t)Aout * B;
+        if (g.bpk) {
+            for (size_t i = threadIdx.x; i < nb; i += blockDim.x) lbp[i] = g.bpk[i];
+        } else {
+            for (size_t i = threadIdx.x; i < nb; i += blockDim.x) {
+                const int px = g.xp[i], py = g.yp[i];
+                lbw[i] = (px < 0 || py < 0 || px > 255 || py > 255) ? (unsigned short)0xFFFF : (unsigned short)((px << 8) | py);
+            }
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        int xx = xs, yy = ys, n = 0, err = 0;
+        int xx = g.xs, yy = g.ys, n = 0, err = 0;
         for (;;) {
+            if (xx == 0 && yy == 0) break;
             const int aa = xx + yy;
-            if (aa < 0 || aa >= Aout) { err = SVX_ERR_TRACEBACK; break; }
-            const int bb = yy - boff[aa];
+            if (aa < 0 || aa >= Aout || n >= cap - 1) { err = SVX_ERR_TRACEBACK; break; }
+            const int bb = yy - (g.use_lds ? lbo[aa] : g.boff[aa]);
             if (bb < 0 || bb >= B) { err = SVX_ERR_TRACEBACK; break; }
             const size_t o = (size_t)aa * B + bb;
-            scores[cap - 1 - n] = csum[o];
-            if (xx == 0 && yy == 0) break;
-            if (n >= cap - 1) { err = SVX_ERR_TRACEBACK; break; }
-            const int px = xp[o], py = yp[o];
-            if (px < 0 || py < 0 || (px == 0 && py == 0)) { err = SVX_ERR_TRACEBACK; break; }
-            int* r = align + 4 * (size_t)(cap - 1 - n);
+            int px, py;
+            if (g.bpk) {
+                const unsigned char v = g.use_lds ? lbp[o] : g.bpk[o];
+                px = v == 0xFF ? -42 : (v >> 4);
+                py = v == 0xFF ? -42 : (v & 15);
+            } else if (g.use_lds) {
+                const unsigned short v = lbw[o];
+                px = v == 0xFFFF ? -42 : (v >> 8);
+                py = v == 0xFFFF ? -42 : (v & 255);
+            } else {
+                px = g.xp[o];
+                py = g.yp[o];
+            }
+            if (px < 0 || py < 0 || (px == 0 && py == 0) || px > xx || py > yy) { err = SVX_ERR_TRACEBACK; break; }
+            int* r = g.align + 4 * (size_t)(cap - 1 - n);
             r[0] = xx - px; r[1] = px; r[2] = yy - py; r[3] = py;
             xx -= px;
             yy -= py;
             n++;
+        }
+        if (!err) {  // the end node itself must be inside the band (the reference indexes it first)
+            const int aa = g.xs + g.ys;
+            const int bb = (aa >= 0 && aa < Aout) ? g.ys - g.boff[aa] : -1;
+            if (bb < 0 || bb >= B) err = SVX_ERR_TRACEBACK;
         }
         sh_n = err ? -err : n;
     }
@@ -252,60 +485,67 @@ __device__ void sparse_traceback_block(const double* csum, const int* xp, const 
     const int n = sh_n;
     if (n < 0) {
         if (threadIdx.x == 0) {
-            *count = n;
-            if (status) *status = -n;
+            *g.count = n;
+            if (g.status) *g.status = -n;
         }
         return;
     }
-    // rows: alignment j (document order) sits at row cap-n+j.  cum: c_j sits at scores[cap-1-n+j],
-    // j = 0..n (c_0 at node (0,0)); cost_j = c_{j+1} - c_j.
+    // alignment j (document order) sits at row cap-n+j; its cost is csum[end node] - csum[start node]
     const int nt = blockDim.x;
     for (int base = 0; base < n; base += nt) {
         const int j = base + threadIdx.x;
         int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         double s = 0.0;
         if (j < n) {
-            const int* r = align + 4 * (size_t)(cap - n + j);
+            const int* r = g.align + 4 * (size_t)(cap - n + j);
             r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3];
-            const double cost = scores[cap - 1 - n + j + 1] - scores[cap - 1 - n + j];
+            const int xa = r0, ya = r2, xb = r0 + r1, yb = r2 + r3;
+            const double c0 = g.csum[(size_t)(xa + ya) * B + (ya - g.boff[xa + ya])];
+            const double c1 = g.csum[(size_t)(xb + yb) * B + (yb - g.boff[xb + yb])];
+            const double cost = c1 - c0;
             s = cost < 0.0 ? 0.0 : cost;  // np.clip(a_min=0)
             if (r1 == 0 || r3 == 0) s = 0.0;
             else s = s / (double)r1 / (double)r3;
         }
         __syncthreads();
         if (j < n) {
-            int* w = align + 4 * (size_t)j;
+            int* w = g.align + 4 * (size_t)j;
             w[0] = r0; w[1] = r1; w[2] = r2; w[3] = r3;
-            scores[j] = s;
+            g.scores[j] = s;
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *count = n;
+    if (threadIdx.x == 0) *g.count = n;
 }
 
-__global__ __launch_bounds__(64) void k_sparse_traceback(const double* csum, const int* xp, const int* yp, const int* boff,
-                                                         int Aout, int B, int xs, int ys, int* align, double* scores,
-                                                         int* count) {
-    sparse_traceback_block(csum, xp, yp, boff, Aout, B, xs, ys, align, scores, count, nullptr);
+__global__ __launch_bounds__(256) void k_sparse_traceback(TbArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    sparse_traceback_block(g, smem);
 }
 
-__global__ __launch_bounds__(64) void k_sparse_traceback_batch(const SvxPairDev* __restrict__ pairs, int depth, int B) {
+__global__ __launch_bounds__(256) void k_sparse_traceback_batch(const SvxPairDev* __restrict__ pairs, int depth, int B,
+                                                                int lds_cap_aout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const SvxPairDev& P = pairs[blockIdx.x];
     if (depth > P.L || (depth == P.L && P.L > 0)) return;
     if (*P.status != 0) return;
     const SvxLevel& Lv = P.lev[depth];
     const int A = *Lv.path_len;
     if (A <= 0) return;
-    sparse_traceback_block(Lv.csum, Lv.xp, Lv.yp, Lv.boff_out, A + 2, B, Lv.n[0], Lv.n[1], Lv.align, Lv.scores, Lv.n_align,
-                           P.status);
+    TbArgs g;
+    g.csum = Lv.csum; g.xp = Lv.xp; g.yp = Lv.yp; g.bpk = Lv.bpk; g.boff = Lv.boff_out;
+    g.Aout = A + 2; g.B = B; g.xs = Lv.n[0]; g.ys = Lv.n[1];
+    g.align = Lv.align; g.scores = Lv.scores; g.count = Lv.n_align; g.status = P.status;
+    g.use_lds = (A + 2) <= lds_cap_aout;
+    sparse_traceback_block(g, smem);
 }
 
 // ------------------------------------------------------------------------------ search path
 // append_slant (dp_utils.py:177-196); python round() is round-half-even = rint in the default mode
-__device__ int slant(int* path, int n, int cap, int xw, int yw) {
+__device__ int slant(int* path, int n, int cap, int xw, int yw, int& lx, int& ly) {
+    // (lx, ly) = path[n-1], carried in registers so that the walk never reads back what it wrote
     const int NN = xw + yw;
-    const int xs = path[2 * (n - 1)], ys = path[2 * (n - 1) + 1];
-    int lx = xs, ly = ys;
+    const int xs = lx, ys = ly;
     for (int ii = 1; ii <= NN; ii++) {
         const int x = xs + (int)rint((double)((long long)xw * ii) / (double)NN);
         const int y = ys + (int)rint((double)((long long)yw * ii) / (double)NN);
@@ -316,8 +556,7 @@ __device__ int slant(int* path, int n, int cap, int xw, int yw) {
         else if (delta == 0) { nx = x + 1; ny = y; }
         else continue;
         if (n >= cap) return -SVX_ERR_PATH;
-        path[2 * n] = nx;
-        path[2 * n + 1] = ny;
+        *reinterpret_cast<int2*>(path + 2 * (size_t)n) = make_int2(nx, ny);
         lx = nx;
         ly = ny;
         n++;
@@ -331,18 +570,19 @@ __device__ int search_path_thread(const int* align, int n_align, int upsample, i
     int n = 1, xdel = 0, ydel = 0;
     const int f = upsample ? 2 : 1;
     int xmax = 0, ymax = 0;
+    int lx = 0, ly = 0;
     path[0] = 0;
     path[1] = 0;
     for (int i = 0; i < n_align; i++) {
-        const int* r = align + 4 * (size_t)i;
-        const int p = r[1] * f, q = r[3] * f;
-        if (r[1] > 0) { const int m = (r[0] + r[1]) * f - 1; if (m > xmax) xmax = m; }
-        if (r[3] > 0) { const int m = (r[2] + r[3]) * f - 1; if (m > ymax) ymax = m; }
+        const int4 r = *reinterpret_cast<const int4*>(align + 4 * (size_t)i);
+        const int p = r.y * f, q = r.w * f;
+        if (r.y > 0) { const int m = (r.x + r.y) * f - 1; if (m > xmax) xmax = m; }
+        if (r.w > 0) { const int m = (r.z + r.w) * f - 1; if (m > ymax) ymax = m; }
         if (p > 0 && q > 0) {
-            n = slant(path, n, cap, xdel, ydel);
+            n = slant(path, n, cap, xdel, ydel, lx, ly);
             if (n < 0) return n;
             xdel = 0; ydel = 0;
-            n = slant(path, n, cap, p, q);
+            n = slant(path, n, cap, p, q, lx, ly);
             if (n < 0) return n;
         } else if (p > 0) xdel += p;
         else if (q > 0) ydel += q;
@@ -353,41 +593,138 @@ __device__ int search_path_thread(const int* align, int n_align, int upsample, i
         if (ex == 0) ydel += ey;
         else if (ey == 0) xdel += ex;
         else {
-            n = slant(path, n, cap, xdel, ydel);
+            n = slant(path, n, cap, xdel, ydel, lx, ly);
             if (n < 0) return n;
             xdel = 0; ydel = 0;
-            n = slant(path, n, cap, ex, ey);
+            n = slant(path, n, cap, ex, ey, lx, ly);
             if (n < 0) return n;
         }
     }
-    return slant(path, n, cap, xdel, ydel);
+    return slant(path, n, cap, xdel, ydel, lx, ly);
 }
 
-__global__ void k_search_path(const int* align, const int* n_align, int upsample, int size0, int size1, int* path,
-                              int cap, int* path_len) {
-    if (threadIdx.x == 0) {
-        const int na = *n_align;
-        *path_len = na < 0 ? na : search_path_thread(align, na, upsample, size0, size1, path, cap);
+// Parallel form.  A slant never looks at more of the path than the SUM x+y of the last point, and
+// that sum grows by exactly one per appended point, so point number a of the path is a pure function
+// of the slant that contains it: thread 0 only lists the slants (start offset, start x), then all
+// threads evaluate the points independently.  LDS: dx, dy [R+1] and slant offsets / x [R+3].
+__host__ __device__ inline size_t sp_smem_bytes(int rows) { return (size_t)(2 * (rows + 1) + 2 * (rows + 3)) * sizeof(int); }
+
+__device__ void search_path_block(const int* align, int n_align, int upsample, int size0, int size1, int* path, int cap,
+                                  int* path_len, int* status, char* smem) {
+    __shared__ int sh_xmax, sh_ymax, sh_nseg, sh_A;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int R = n_align, f = upsample ? 2 : 1;
+    int* dx = reinterpret_cast<int*>(smem);
+    int* dy = dx + (R + 1);
+    int* soff = dy + (R + 1);
+    int* sxs = soff + (R + 3);
+    if (tid == 0) { sh_xmax = 0; sh_ymax = 0; }
+    __syncthreads();
+    for (int i = tid; i < R; i += nt) {
+        const int4 r = *reinterpret_cast<const int4*>(align + 4 * (size_t)i);
+        dx[i] = r.y * f;
+        dy[i] = r.w * f;
+        if (r.y > 0) atomicMax(&sh_xmax, (r.x + r.y) * f - 1);
+        if (r.w > 0) atomicMax(&sh_ymax, (r.z + r.w) * f - 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int Rr = R, err = 0;
+        if (upsample) {
+            const int xmax = sh_xmax, ymax = sh_ymax;
+            if (xmax > size0 || ymax > size1) err = SVX_ERR_EXTEND;
+            dx[Rr] = size0 - xmax;  // extend_alignments: (extra_x, extra_y) as one more row; an empty side
+            dy[Rr] = size1 - ymax;  //  turns it into a deletion row, exactly like the reference's branches
+            Rr++;
+        }
+        int nseg = 0, off = 1, x = 0, xdel = 0, ydel = 0;
+        for (int i = 0; i < Rr && !err; i++) {
+            const int p = dx[i], q = dy[i];
+            if (p > 0 && q > 0) {
+                if (xdel + ydel > 0) {
+                    soff[nseg] = off; sxs[nseg] = x; nseg++;
+                    off += xdel + ydel; x += xdel;
+                    xdel = 0; ydel = 0;
+                }
+                soff[nseg] = off; sxs[nseg] = x; nseg++;
+                off += p + q; x += p;
+            } else {
+                xdel += p;
+                ydel += q;
+            }
+        }
+        if (xdel + ydel > 0) {
+            soff[nseg] = off; sxs[nseg] = x; nseg++;
+            off += xdel + ydel; x += xdel;
+        }
+        soff[nseg] = off;  // sentinel: total number of points
+        sxs[nseg] = x;
+        if (!err && off > cap) err = SVX_ERR_PATH;
+        sh_nseg = nseg;
+        sh_A = err ? -err : off;
+    }
+    __syncthreads();
+    const int A = sh_A, nseg = sh_nseg;
+    if (A < 0) {
+        if (tid == 0) { *path_len = A; if (status) *status = -A; }
+        return;
+    }
+    if (tid == 0) { path[0] = 0; path[1] = 0; }
+    for (int a = 1 + tid; a < A; a += nt) {
+        int lo = 0, hi = nseg - 1;  // largest k with soff[k] <= a
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (soff[mid] <= a) lo = mid; else hi = mid - 1;
+        }
+        const int o0 = soff[lo], xs = sxs[lo], ys = o0 - 1 - xs;
+        const int NN = soff[lo + 1] - o0, xw = sxs[lo + 1] - xs, yw = NN - xw;
+        const int ii = a - o0 + 1;
+        const int rx = (int)rint((double)((long long)xw * ii) / (double)NN);
+        const int ry = (int)rint((double)((long long)yw * ii) / (double)NN);
+        const int delta = rx + ry - ii + 1;  // x + y - (sum of the previous point)
+        const int px = xs + rx + (delta == 2 ? -1 : (delta == 0 ? 1 : 0));
+        *reinterpret_cast<int2*>(path + 2 * (size_t)a) = make_int2(px, ys + ry);
+    }
+    if (tid == 0) *path_len = A;
+}
+
+__global__ __launch_bounds__(256) void k_search_path(const int* align, const int* n_align, int upsample, int size0, int size1,
+                                                     int* path, int cap, int* path_len, int lds_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int na = *n_align;
+    if (na < 0) {
+        if (threadIdx.x == 0) *path_len = na;
+        return;
+    }
+    if (na <= lds_rows) {
+        search_path_block(align, na, upsample, size0, size1, path, cap, path_len, nullptr, smem);
+    } else if (threadIdx.x == 0) {
+        *path_len = search_path_thread(align, na, upsample, size0, size1, path, cap);
     }
 }
 
-__global__ void k_search_path_batch(const SvxPairDev* __restrict__ pairs, int depth) {
+__global__ __launch_bounds__(256) void k_search_path_batch(const SvxPairDev* __restrict__ pairs, int depth, int lds_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const SvxPairDev& P = pairs[blockIdx.x];
-    if (threadIdx.x != 0) return;
     if (depth > P.L || (depth == P.L && P.L > 0)) return;
     if (*P.status != 0) return;
     const SvxLevel& dst = P.lev[depth];
     const SvxLevel& src = P.lev[P.L == 0 ? 0 : depth + 1];
     const int na = *src.n_align;
-    int n = na < 0 ? na : search_path_thread(src.align, na, P.L > 0, dst.n[0], dst.n[1], dst.path, dst.path_cap);
-    *dst.path_len = n;
-    if (n < 0) *P.status = -n;
+    if (na >= 0 && na <= lds_rows) {
+        search_path_block(src.align, na, P.L > 0, dst.n[0], dst.n[1], dst.path, dst.path_cap, dst.path_len, P.status, smem);
+    } else if (threadIdx.x == 0) {
+        int n = na < 0 ? na : search_path_thread(src.align, na, P.L > 0, dst.n[0], dst.n[1], dst.path, dst.path_cap);
+        *dst.path_len = n;
+        if (n < 0) *P.status = -n;
+    }
 }
 
 // ------------------------------------------------------------------------------ deletion penalty
 // DeletionKnob (dp_utils.py:50-79) with numpy's arithmetic: float32 bin edges i*(max/1000),
 // density histogram, float64 cdf, 27 interior knots k/28, np.interp at `frac`.
 __device__ void del_penalty_block(const float* scores, long long n, double frac, double* out) {
+#pragma clang fp contract(off)  // numpy rounds every multiply and add separately
     __shared__ float edges[1001];
     __shared__ int cnt[1000];
     __shared__ float red[256];
@@ -451,6 +788,7 @@ __device__ void del_penalty_block(const float* scores, long long n, double frac,
             while (j < 28 && xs[j + 1] <= frac) j++;
             if (j == 28 || xs[j] == frac) res = ys[j];
             else {
+                // numpy evaluates slope*(x - xp[j]) + fp[j] as a separate multiply and add: no FMA contraction
                 const double slope = (ys[j + 1] - ys[j]) / (xs[j + 1] - xs[j]);
                 res = slope * (frac - xs[j]) + ys[j];
                 if (res != res) {
@@ -510,10 +848,27 @@ int svxl_dense_traceback(svx_ctx* ctx, const int* bp, int s0, int s1, int* align
     return SVX_OK;
 }
 
+static int dpf_choose_ch(int T, int B, int maxstep) {
+    if (B > 64 || maxstep > 120) return 0;  // transitions are packed into 8-bit fields
+    const int opts[4] = {64, 32, 16, 8};
+    for (int i = 0; i < 4; i++)
+        if (dpf_smem_bytes(T, B, maxstep + 1, opts[i]) <= 120 * 1024) return opts[i];
+    return 0;
+}
+
 int svxl_sparse_dp(svx_ctx* ctx, const float* costs, const int* boff_in, int A, int B, const SvxTypes& types, double pen,
                    int xs, int ys, double* csum, int* xp, int* yp, int* boff_out) {
     if (A <= 0 || B <= 0) return SVX_OK;
-    SparseDpArgs g{costs, boff_in, A, B, pen, xs, ys, csum, xp, yp, boff_out};
+    SparseDpArgs g{costs, boff_in, A, B, pen, xs, ys, csum, xp, yp, nullptr, boff_out, 0};
+    const int CH = dpf_choose_ch(types.n, B, types.maxstep);
+    if (CH > 0) {
+        const size_t smem = dpf_smem_bytes(types.n, B, types.maxstep + 1, CH);
+        if (smem > 64 * 1024)
+            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_dp_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(k_sparse_dp_fast, dim3(1), dim3(DPF_THREADS), smem, ctx->stream, g, types, CH);
+        SVX_LAUNCH_CHECK(ctx, "k_sparse_dp_fast");
+        return SVX_OK;
+    }
     const size_t smem = (size_t)(types.maxstep + 1) * B * sizeof(double);
     const int nt = dp_threads(B);
     if (smem <= 150 * 1024) {
@@ -529,6 +884,15 @@ int svxl_sparse_dp(svx_ctx* ctx, const float* costs, const int* boff_in, int A, 
 
 int svxl_sparse_dp_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int depth, const SvxTypes& types, int B) {
     if (n_pairs <= 0) return SVX_OK;
+    const int CH = dpf_choose_ch(types.n, B, types.maxstep);
+    if (CH > 0) {
+        const size_t smem = dpf_smem_bytes(types.n, B, types.maxstep + 1, CH);
+        if (smem > 64 * 1024)
+            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_dp_fast_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(k_sparse_dp_fast_batch, dim3(n_pairs), dim3(DPF_THREADS), smem, ctx->stream, pairs, depth, types, B, CH);
+        SVX_LAUNCH_CHECK(ctx, "k_sparse_dp_fast_batch");
+        return SVX_OK;
+    }
     const size_t smem = (size_t)(types.maxstep + 1) * B * sizeof(double);
     const int nt = dp_threads(B);
     if (smem <= 150 * 1024) {
@@ -542,32 +906,67 @@ int svxl_sparse_dp_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int
     return SVX_OK;
 }
 
+static const size_t TB_LDS_LIMIT = 150 * 1024;
+
 int svxl_sparse_traceback(svx_ctx* ctx, const double* csum, const int* xp, const int* yp, const int* boff, int a_out, int B,
                           int xs, int ys, int* align, double* scores, int* count) {
-    hipLaunchKernelGGL(k_sparse_traceback, dim3(1), dim3(64), 0, ctx->stream, csum, xp, yp, boff, a_out, B, xs, ys, align,
-                       scores, count);
+    TbArgs g;
+    g.csum = csum; g.xp = xp; g.yp = yp; g.bpk = nullptr; g.boff = boff;
+    g.Aout = a_out; g.B = B; g.xs = xs; g.ys = ys;
+    g.align = align; g.scores = scores; g.count = count; g.status = nullptr;
+    size_t smem = tb_smem_bytes(a_out, B, true);
+    g.use_lds = smem <= TB_LDS_LIMIT;
+    if (!g.use_lds) smem = 0;
+    if (smem > 64 * 1024)
+        SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_traceback, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(k_sparse_traceback, dim3(1), dim3(256), smem, ctx->stream, g);
     SVX_LAUNCH_CHECK(ctx, "k_sparse_traceback");
     return SVX_OK;
 }
 
-int svxl_sparse_traceback_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int depth, int B) {
+int svxl_sparse_traceback_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int depth, int B, int max_A, int packed) {
     if (n_pairs <= 0) return SVX_OK;
-    hipLaunchKernelGGL(k_sparse_traceback_batch, dim3(n_pairs), dim3(64), 0, ctx->stream, pairs, depth, B);
+    // LDS for the largest pair that still fits; larger pairs in the batch chase pointers in global memory
+    // (pairs whose types do not pack into bytes hold 16-bit entries: budget for those)
+    int cap_aout = (int)(TB_LDS_LIMIT / (sizeof(int) + 2 * (size_t)B));
+    if (packed) cap_aout = (int)(TB_LDS_LIMIT / (sizeof(int) + (size_t)B));
+    if (cap_aout > max_A + 2) cap_aout = max_A + 2;
+    const size_t smem = tb_smem_bytes(cap_aout, B, !packed);
+    if (smem > 64 * 1024)
+        SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_traceback_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(k_sparse_traceback_batch, dim3(n_pairs), dim3(256), smem, ctx->stream, pairs, depth, B, cap_aout);
     SVX_LAUNCH_CHECK(ctx, "k_sparse_traceback_batch");
     return SVX_OK;
 }
 
+static const size_t SP_LDS_LIMIT = 150 * 1024;
+
+static int sp_lds_rows(int max_rows, size_t* smem) {
+    int rows = max_rows;
+    if (sp_smem_bytes(rows) > SP_LDS_LIMIT) rows = (int)(SP_LDS_LIMIT / (4 * sizeof(int))) - 3;
+    *smem = sp_smem_bytes(rows);
+    return rows;
+}
+
 int svxl_search_path(svx_ctx* ctx, const int* align, const int* n_align, int upsample, int size0, int size1, int* path,
                      int cap, int* path_len) {
-    hipLaunchKernelGGL(k_search_path, dim3(1), dim3(64), 0, ctx->stream, align, n_align, upsample, size0, size1, path, cap,
-                       path_len);
+    size_t smem;
+    const int rows = sp_lds_rows(size0 + size1 + 2, &smem);
+    if (smem > 64 * 1024)
+        SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_search_path, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(k_search_path, dim3(1), dim3(256), smem, ctx->stream, align, n_align, upsample, size0, size1, path, cap,
+                       path_len, rows);
     SVX_LAUNCH_CHECK(ctx, "k_search_path");
     return SVX_OK;
 }
 
-int svxl_search_path_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int depth) {
+int svxl_search_path_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int depth, int max_rows) {
     if (n_pairs <= 0) return SVX_OK;
-    hipLaunchKernelGGL(k_search_path_batch, dim3(n_pairs), dim3(64), 0, ctx->stream, pairs, depth);
+    size_t smem;
+    const int rows = sp_lds_rows(max_rows, &smem);
+    if (smem > 64 * 1024)
+        SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_search_path_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(k_search_path_batch, dim3(n_pairs), dim3(256), smem, ctx->stream, pairs, depth, rows);
     SVX_LAUNCH_CHECK(ctx, "k_search_path_batch");
     return SVX_OK;
 }

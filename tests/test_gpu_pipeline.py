@@ -1,0 +1,127 @@
+"""Whole-path parity on the GPU (svx_align_batch through svx.vecalign.dp_utils.vecalign):
+  * golden vectors produced by the REAL reference (tests/golden/pipeline.npz) -- identical alignment
+    spans, scores within 1e-4 (BASELINE.json north_star tolerance), deletion penalties within 5e-5;
+  * the CPU oracle at the benchmark size (4096 x 4096, d = 1024, bf16);
+  * size-independent properties: batch invariance, ragged batches, idempotence, seed handling.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from cases import PIPELINE_CASES, pipeline_inputs
+from synth import alignment_types, make_pair, round_bf16
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "pipeline.npz")
+SCORE_TOL = 1e-4
+
+
+def to_dev(v, dt):
+    import torch
+    t = torch.from_numpy(v).cuda()
+    return {"f32": t, "f16": t.half(), "bf16": t.bfloat16()}[dt]
+
+
+def rows(al):
+    out = np.zeros((len(al), 4), np.int32)
+    for i, (x, y) in enumerate(al):
+        out[i] = (x[0] if x else 0, len(x), y[0] if y else 0, len(y))
+    return out
+
+
+@pytest.mark.parametrize("name", list(PIPELINE_CASES))
+def test_vecalign_vs_reference_golden(name):
+    from svx.vecalign import dp_utils
+    gold = np.load(GOLD)
+    c = PIPELINE_CASES[name]
+    v0, v1, types, W, kw = pipeline_inputs(c)
+    np.random.seed(c["rng_seed"])
+    stack = dp_utils.vecalign(to_dev(v0, kw["dtype"]), to_dev(v1, kw["dtype"]), types, c.get("frac", 0.2), W,
+                              c.get("max_full", 300), c.get("sample", 20000), c.get("nsamp", 100))
+    pens = np.array([stack[d]['del_penalty'] for d in sorted(stack)])
+    assert len(pens) == len(gold[name + "/del_pen"])
+    assert np.abs(pens - gold[name + "/del_pen"]).max() < 5e-5
+    got = rows(stack[0]['final_alignments'])
+    assert got.shape == gold[name + "/align"].shape and np.array_equal(got[:, [1, 3]], gold[name + "/align"][:, [1, 3]])
+    keep = (got[:, 1] > 0) & (got[:, 3] > 0)  # a deletion's start index is not defined by the reference (empty list)
+    assert np.array_equal(got[keep], gold[name + "/align"][keep])
+    assert np.abs(stack[0]['alignment_scores'] - gold[name + "/scores"]).max() < SCORE_TOL
+
+
+def test_benchmark_size_vs_oracle(orc):
+    """BASELINE configs[1]: 4096 x 4096, d = 1024, bf16, 4 overlap layers (10 types, band 14)."""
+    import torch
+    from svx.vecalign import dp_utils
+    K, a = 4, 5
+    types = alignment_types(a)
+    W = int(np.ceil(K / 2.0)) + 5
+    pairs, hosts = [], []
+    for i in range(2):
+        v0, v1 = make_pair(4096, 4096 - 37 * i, K, 1024, 100 + i, deletions=40 * i)
+        v0, v1 = round_bf16(v0), round_bf16(v1)
+        hosts.append((v0, v1))
+        pairs.append((torch.from_numpy(v0).cuda().bfloat16(), torch.from_numpy(v1).cuda().bfloat16()))
+    rngs = [np.random.RandomState(50 + i) for i in range(2)]
+    res = dp_utils.align_batch(pairs, types, 0.2, W, 300, 20000, 100, rngs=rngs)
+    for i, (v0, v1) in enumerate(hosts):
+        ref = orc.vecalign(v0.copy(), v1.copy(), types, 0.2, W, 300, 20000, 100, rng=np.random.RandomState(50 + i))
+        assert res[i][0] == ref[0]['final_alignments']
+        assert np.abs(res[i][1] - ref[0]['alignment_scores']).max() < SCORE_TOL
+        assert len(ref) == 5 and np.abs(res[i][2] - np.array([ref[d]['del_penalty'] for d in range(5)])).max() < 5e-5
+
+
+def test_batch_invariance_and_idempotence():
+    """A pair's result does not depend on which other pairs share its batch, nor on repetition."""
+    from svx.vecalign import dp_utils
+    types = alignment_types(5)
+    shapes = [(700, 650), (90, 1300), (1500, 1400), (300, 280), (2049, 1999)]
+    docs = [make_pair(n, m, 4, 64, 30 + i) for i, (n, m) in enumerate(shapes)]
+
+    def rng(i):
+        return np.random.RandomState(1000 + i)
+    batch = dp_utils.align_batch(docs, types, 0.2, 7, 300, 20000, 100, rngs=[rng(i) for i in range(len(docs))])
+    again = dp_utils.align_batch(docs, types, 0.2, 7, 300, 20000, 100, rngs=[rng(i) for i in range(len(docs))])
+    for i in range(len(docs)):
+        single = dp_utils.align_batch([docs[i]], types, 0.2, 7, 300, 20000, 100, rngs=[rng(i)])[0]
+        assert single[0] == batch[i][0] == again[i][0]
+        assert np.array_equal(single[1], batch[i][1]) and np.array_equal(again[i][1], batch[i][1])
+        assert np.array_equal(single[2], batch[i][2])
+        # every segment is covered exactly once, in order
+        xs = [x for al in batch[i][0] for x in al[0]]
+        ys = [y for al in batch[i][0] for y in al[1]]
+        assert xs == list(range(shapes[i][0])) and ys == list(range(shapes[i][1]))
+
+
+def test_norm_overrides_and_global_stream(orc):
+    """norms0/norms1 overrides (dp_utils.py:428-444) skip the corresponding random draws."""
+    from svx.vecalign import dp_utils
+    v0, v1 = make_pair(400, 380, 3, 64, 77)
+    types = alignment_types(4)
+    a, b = v0.copy(), v1.copy()
+    orc.make_norm1(a)
+    orc.make_norm1(b)
+    n0 = orc.compute_norms(a, b, 100, np.random.RandomState(4))
+    np.random.seed(8)
+    ref = orc.vecalign(v0.copy(), v1.copy(), types, 0.2, 7, 300, 20000, 100, norms0=n0)
+    np.random.seed(8)
+    got = dp_utils.vecalign(v0, v1, types, 0.2, 7, 300, 20000, 100, norms0=n0)
+    assert got[0]['final_alignments'] == ref[0]['final_alignments']
+    assert np.abs(got[0]['alignment_scores'] - ref[0]['alignment_scores']).max() < SCORE_TOL
+    with pytest.raises(Exception, match="norms0 wrong shape"):
+        dp_utils.vecalign(v0, v1, types, 0.2, 7, 300, 20000, 100, norms0=n0[:, :-1])
+
+
+def test_degenerate_documents(orc):
+    from svx.vecalign import dp_utils
+    types = alignment_types(3)
+    for n, m in [(1, 1), (1, 9), (12, 1), (2, 3)]:
+        v0, v1 = make_pair(n, m, 2, 64, 5)
+        np.random.seed(1)
+        ref = orc.vecalign(v0.copy(), v1.copy(), types, 0.2, 6, 300, 20000, 100)
+        np.random.seed(1)
+        got = dp_utils.vecalign(v0, v1, types, 0.2, 6, 300, 20000, 100)
+        assert got[0]['final_alignments'] == ref[0]['final_alignments'], (n, m)
+        assert np.abs(got[0]['alignment_scores'] - ref[0]['alignment_scores']).max() < SCORE_TOL
+    with pytest.raises(Exception, match=r"4 x overlaps requrested \(via alignment_types\), but vecs0 only has 2"):
+        dp_utils.vecalign(*make_pair(30, 30, 2, 64, 5), alignment_types(5), 0.2, 7, 300, 20000, 100)

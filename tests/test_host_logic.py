@@ -1,0 +1,206 @@
+"""Host-side logic of the path (no GPU): alignment types, search parameters, file formats, candidate
+index tables, scoring, sharding, CLI surface.  Where the reference is present (build container) the
+results are compared with the reference's own functions; otherwise with fixtures / known answers."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ref_loader  # noqa: E402
+
+TRIM = os.path.join(ROOT, "tests", "golden", "example_trim")
+needs_ref = pytest.mark.skipif(not ref_loader.available(), reason="reference not present (GPU box)")
+
+
+def test_alignment_types_and_search_params():
+    from svx.vecalign import vecalign as V
+    assert V.make_alignment_types(3) == [(1, 1), (1, 2), (2, 1)]
+    assert len(V.make_alignment_types(6)) == 15 and len(V.make_alignment_types(5)) == 10
+    assert V.make_alignment_types(4) == [(1, 1), (1, 2), (1, 3), (2, 1), (2, 2), (3, 1)]
+    assert V.make_many_to_one_alignment_types(3) == [(1, 1), (2, 1), (3, 1)]
+    types, sk, tk, W = V.resolve_search_params(6, None, 5)
+    assert (len(types), sk, tk, W) == (15, 5, 5, 8)
+    types, sk, tk, W = V.resolve_search_params(5, None, 5)
+    assert (len(types), sk, tk, W) == (10, 4, 4, 7)
+    types, sk, tk, W = V.resolve_search_params(1, None, 5)  # clamped to 2 (vecalign.py:230-232)
+    assert (types, sk, tk, W) == ([(1, 1)], 1, 1, 6)
+    types, sk, tk, W = V.resolve_search_params(10, 4, 5)
+    assert (types, sk, tk, W) == ([(1, 1), (2, 1), (3, 1), (4, 1)], 4, 1, 7)
+
+
+@needs_ref
+def test_types_match_reference():
+    from svx.vecalign import vecalign as V
+    ref = ref_loader.load()
+    for a in range(2, 12):
+        assert V.make_alignment_types(a) == ref.vecalign.make_alignment_types(a)
+        assert V.make_many_to_one_alignment_types(a) == ref.vecalign.make_many_to_one_alignment_types(a)
+
+
+def test_alignment_files_round_trip(tmp_path):
+    from svx.utils import file_utils as F
+    from svx.vecalign.vecalign import print_alignments
+    al = [([0, 1], [0]), ([], [1]), ([2], [2, 3, 4]), ([3], [])]
+    sc = [0.349737, 0.0, 1.25, 0.0]
+    p = tmp_path / "a.txt"
+    with open(p, "w") as fp:
+        print_alignments(al, scores=sc, ofile=fp)
+    assert p.read_text().splitlines() == ["[0, 1]:[0]:0.349737", "[]:[1]:0.000000", "[2]:[2, 3, 4]:1.250000", "[3]:[]:0.000000"]
+    assert F.read_alignments(p) == al
+    assert F.read_alignments_with_score(p) == [(a[0], a[1], s) for a, s in zip(al, sc)]
+    F.write_alignment(al, tmp_path / "b.txt")
+    assert F.read_alignments(tmp_path / "b.txt") == al
+    segs = [(0, 10), (10, 25), (30, 40), (41, 50)]
+    s, t, n = F.alignments_to_timestamps(al, segs, [(0, 5), (6, 9), (9, 12), (12, 20), (21, 30)])
+    assert n == 2 and s == [(0, 25), (30, 40)] and t == [(0, 5), (9, 30)]
+    exp = F.read_alignments_with_score(os.path.join(TRIM, "expected_seed0.txt"))
+    assert len(exp) > 20 and all(len(e) == 3 for e in exp)
+    assert F.read_segments(os.path.join(TRIM, "segments_en.txt"))[0][0] >= 0
+    with pytest.raises(Exception, match="does not have at least two"):
+        (tmp_path / "c.txt").write_text("garbage\n")
+        F.read_alignments(tmp_path / "c.txt")
+
+
+def _load_trim(lang):
+    from svx.utils import embedding_utils as E
+    s2i, emb = E.read_in_embeddings(os.path.join(TRIM, f"cat_segs_{lang}.txt"), os.path.join(TRIM, f"embeds_{lang}.f16"), False, True)
+    lines = open(os.path.join(TRIM, f"segments_{lang}.txt")).readlines()
+    return s2i, emb, lines
+
+
+def test_candidate_index_table_fixture():
+    from svx.utils import embedding_utils as E
+    from svx.vecalign.vecalign import load_ignore_index_file
+    s2i, emb, lines = _load_trim("en")
+    assert emb.dtype == np.float16 and emb.shape[1] == 1024 and emb.shape[0] == len(s2i)
+    ign = load_ignore_index_file(os.path.join(TRIM, "ignore_src.txt"))
+    tab = E.candidate_index_table(s2i, lines, 5, ign, overlap_segments=True)
+    assert tab.shape == (5, len(lines)) and tab.dtype == np.int32
+    for j in range(5):
+        assert (tab[j, :j] == -1).all()          # PAD triangle: no j+1 segments end before index j
+    assert (tab[0] >= 0).sum() >= len(lines) - len(ign) - 1
+    for (s, j) in ign:                            # an ignore entry zeroes every overlap from (s, j) on
+        for k in range(j - s, min(len(lines), s + 5) - s):
+            assert tab[k, s + k] == -1
+    # stopes files are plain .npy: the loader needs no stopes
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "x.npy"), np.asarray(emb[:7]))
+        os.rename(os.path.join(td, "x.npy"), os.path.join(td, "x.embed"))
+        got = E.load_sent_embeddings(os.path.join(td, "x.embed"), use_stopes=True)
+        assert got.dtype == np.float16 and np.array_equal(np.asarray(got), np.asarray(emb[:7]))
+
+
+@needs_ref
+def test_candidate_tensor_matches_reference():
+    """table + gather == the reference's make_doc_embedding, bit for bit, on the shipped example."""
+    from svx.utils import embedding_utils as E
+    ref = ref_loader.load()
+    ex = os.path.join(ref.root, "example", "voxpopuli")
+    stem = "20180313-0900-PLENARY-15"
+    for lang, side in (("en", "src"), ("de", "tgt")):
+        cat = os.path.join(ex, "cat_segs", lang, f"{stem}_{lang}.txt")
+        s2i, emb = E.read_in_embeddings(cat, os.path.join(ex, "embeds", lang, f"{stem}_{lang}.embed"), use_stopes=True)
+        lines = open(os.path.join(ex, "segments", lang, f"{stem}_{lang}.txt")).readlines()
+        ign = ref.vecalign.load_ignore_index_file(os.path.join(ex, "untrans_cat_seg_ids", "en-de", f"{stem}_en-{stem}_de.{side}.txt"))
+        tab = E.candidate_index_table(s2i, lines, 5, ign, overlap_segments=True)
+        mine = np.where(tab[..., None] >= 0, np.asarray(emb, dtype=np.float32)[np.clip(tab, 0, None)], 0.0).astype(np.float32)
+        r_s2i = {}
+        for i, l in enumerate(open(cat)):
+            r_s2i.setdefault(l.strip(), i)
+        theirs = ref.embedding_utils.make_doc_embedding(r_s2i, np.asarray(emb, dtype=np.float32), lines, 5, ignore_indices=ign,
+                                                        overlap_segments=True)
+        assert np.array_equal(mine, theirs)
+
+
+@needs_ref
+def test_score_reproduces_readme_tables():
+    """README.md:289-295 / 318-325 quality tables from the shipped alignment files."""
+    from svx.utils.file_utils import read_alignments
+    from svx.vecalign.score import score_multiple
+    ref = ref_loader.load()
+    ex = os.path.join(ref.root, "example", "voxpopuli")
+    stem = "20180313-0900-PLENARY-15"
+    gold = read_alignments(os.path.join(ex, f"{stem}.gold"))
+    name = f"{stem}_en-{stem}_de.txt"
+    for sub, want in (("alignments", (0.558, 0.632, 0.593, 0.942, 0.993, 0.967)), ("align_0.7", (0.593, 0.632, 0.612, 0.972, 0.978, 0.975))):
+        test = read_alignments(os.path.join(ex, sub, "en-de", name))
+        mine = score_multiple([gold], [test])
+        theirs = ref.score.score_multiple(gold_list=[gold], test_list=[test])
+        assert mine == theirs
+        got = (mine["precision_strict"], mine["recall_strict"], mine["f1_strict"], mine["precision_lax"], mine["recall_lax"], mine["f1_lax"])
+        assert all(abs(g - w) < 6e-4 for g, w in zip(got, want))
+
+
+def test_score_small_known_answers():
+    from svx.vecalign.score import score_multiple
+    gold = [([0], [0]), ([1, 2], [1]), ([3], []), ([4], [2, 3])]
+    assert score_multiple([gold], [gold])["f1_strict"] == 1.0
+    test = [([0], [0]), ([1], [1]), ([2], []), ([3], []), ([4], [2]), ([], [3])]
+    r = score_multiple([gold], [test])
+    assert r["precision_strict"] == pytest.approx(2 / 6) and r["precision_lax"] == pytest.approx(4 / 6)
+    assert r["recall_strict"] == pytest.approx(1 / 3) and r["recall_lax"] == 1.0
+    assert score_multiple([[]], [[]])["f1_lax"] == 0.0
+
+
+def test_shards():
+    from svx.utils.mp_utils import balanced_shards, get_shard_range
+    assert [get_shard_range(10, 3, r) for r in range(3)] == [(0, 3), (3, 7), (7, 10)]
+    with pytest.raises(AssertionError):
+        get_shard_range(10, 3, 3)
+    costs = list(np.random.RandomState(0).randint(512, 8192, size=101))
+    for n in (1, 2, 4, 8):
+        sh = balanced_shards(costs, n)
+        assert sorted(i for s in sh for i in s) == list(range(101))
+        loads = [sum(costs[i] for i in s) for s in sh]
+        assert max(loads) - min(loads) <= max(costs)
+    from svx.seg_align.align import pair_rng
+    assert pair_rng(None, 3) is None
+    a, b = pair_rng(7, 3).randint(0, 1 << 30, 5), pair_rng(7, 3).randint(0, 1 << 30, 5)
+    assert np.array_equal(a, b) and not np.array_equal(a, pair_rng(7, 4).randint(0, 1 << 30, 5))
+
+
+def test_cli_surface(tmp_path):
+    """Same flags and defaults as seg_align/align.py:13-96 and vecalign.py:36-151."""
+    from svx.seg_align import align as A
+    from svx.vecalign import vecalign as V
+    a = A.parse_args(["meta.tsv", "out", "--src_lang", "en", "--tgt_lang", "de", "--seg_dir", "s", "--concat_dir", "c", "--embed_dir", "e"])
+    assert (a.alignment_max_size, a.search_buffer_size, a.del_percentile_frac, a.max_size_full_dp, a.costs_sample_size,
+            a.num_samps_for_norm, a.is_stopes_embed, a.fp16_embed, a.ign_indices_dir) == (6, 5, 0.2, 300, 20000, 100, False, False, None)
+    v = V.parse_args(["-s", "a", "-t", "b", "--src_embed", "x", "y", "--tgt_embed", "z", "w"])
+    assert (v.alignment_max_size, v.many_to_one, v.search_buffer_size, v.overlap_segments, v.print_results) == (10, None, 5, False, False)
+    assert V.parse_args(["-s", "a", "-t", "b", "--src_embed", "x", "y", "--tgt_embed", "z", "w", "--many_to_one"]).many_to_one == 50
+    # validate_inputs: directory conventions {dir}/{lang}/{stem}.{txt,embed}, output {out}/{s}-{t}.txt
+    for sub in ("seg/en", "seg/de", "cat/en", "cat/de", "emb/en", "emb/de", "ign"):
+        (tmp_path / sub).mkdir(parents=True)
+    for d, suf in (("seg", ".txt"), ("cat", ".txt"), ("emb", ".embed")):
+        (tmp_path / d / "en" / ("a_en" + suf)).write_text("x")
+        (tmp_path / d / "de" / ("a_de" + suf)).write_text("x")
+    (tmp_path / "ign" / "a_en-a_de.src.txt").write_text("1 2\n")
+    from pathlib import Path
+    got = A.validate_inputs([("/audio/a_en.ogg", "/audio/a_de.ogg"), ("/audio/missing_en.ogg", "/audio/missing_de.ogg")],
+                            tmp_path / "seg/en", tmp_path / "seg/de", tmp_path / "cat/en", tmp_path / "cat/de",
+                            tmp_path / "emb/en", tmp_path / "emb/de", Path("/out/en-de"), tmp_path / "ign")
+    assert len(got) == 1 and got[0].output_path == "/out/en-de/a_en-a_de.txt"
+    assert got[0].src_ignore_indices is not None and got[0].tgt_ignore_indices is None
+    assert got[0].src_embed_path.endswith("emb/en/a_en.embed")
+
+
+def test_draw_indices_layout():
+    """Layout of the sampled-index arrays documented in include/svx.h:svx_pair."""
+    from svx.vecalign import dp_utils
+    sizes = dp_utils.level_sizes(1101, 1003, 300)
+    assert sizes == [(1101, 1003), (550, 501), (275, 250)]
+    ni, ki = dp_utils.draw_indices(1101, 1003, 4, 3, 300, 20000, 100, rng=np.random.RandomState(1))
+    assert len(ni) == sum(3 * 34 + 4 * 25 for _ in sizes) and len(ki) == 2 * 20000 * 3
+    off = 0
+    for s0, s1 in sizes:
+        assert ni[off:off + 3 * 34].max() < s1 and ni[off + 3 * 34:off + 3 * 34 + 4 * 25].max() < s0
+        off += 3 * 34 + 4 * 25
+    ni2, _ = dp_utils.draw_indices(1101, 1003, 4, 3, 300, 20000, 100, rng=np.random.RandomState(1), have_norms0=True)
+    assert len(ni2) == len(ni) - 3 * 34
+    _, ks = dp_utils.draw_indices(90, 80, 2, 2, 300, 20000, 100, rng=np.random.RandomState(1))
+    assert len(ks) == 2 * 7200 and np.array_equal(ks[:80], np.zeros(80)) and np.array_equal(ks[7200:7280], np.arange(80))
