@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu_pairs", type=int, default=4, help="pairs timed on the CPU oracle (rank 0, N=1 only); 0 = skip")
     ap.add_argument("--no_profile", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="internal streams a batch is split over (svx_set_streams)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -106,6 +107,7 @@ def main():
     ctx = pb.ctx
     lib = ctx.lib
 
+    lib.svx_set_streams(ctx.h, args.streams)
     for _ in range(args.warmup):
         pb.run()
     torch.cuda.synchronize()
@@ -113,7 +115,7 @@ def main():
     if not args.no_profile:
         lib.svx_set_profiling(ctx.h, 1)
     stage_names = ["pyr0", "pyrN", "knob_scores", "knob", "dense_costs", "dense_dp", "path", "band_costs0", "band_costsN",
-                   "band_dp0", "band_dpN", "traceback", "setup", "total"]
+                   "band_dp0", "band_dpN", "traceback", "setup", "total", "host_plan", "host_launch"]
     stage_ms = {s: 0.0 for s in stage_names}
     stage_launch = {s: 0 for s in stage_names}
 
@@ -149,7 +151,7 @@ def main():
         "config": {"workload": "synthetic %dx%d d=%d %s embeddings, %d overlap layers/side, %d alignment types, band %d, "
                                "coarse-to-fine (max_size_full_dp=300), %d doc-pairs per GPU per step" %
                                (N, M, d, args.dtype, K, len(types), 2 * W, P),
-                   "pairs_per_step_per_gpu": P, "N": N, "M": M, "d": d, "overlaps": K, "parallelism": "dp%d (pairs sharded, no collective)" % world},
+                   "pairs_per_step_per_gpu": P, "streams": args.streams, "N": N, "M": M, "d": d, "overlaps": K, "parallelism": "dp%d (pairs sharded, no collective)" % world},
         "dp_cells_per_s": value * cells, "dp_cells_per_pair": cells,
     }
 
@@ -157,7 +159,7 @@ def main():
         # ---- roofline of the dominant kernel (HIP events on the launch stream, timed region)
         alg_bytes_pair = K * (N + M) * d * esz  # every candidate embedding read once
         if not args.no_profile and stage_ms["total"] > 0:
-            kernels = {k: v for k, v in stage_ms.items() if k not in ("total", "setup")}
+            kernels = {k: v for k, v in stage_ms.items() if k not in ("total", "setup", "host_plan", "host_launch")}
             dom = max(kernels, key=kernels.get)
             launches = max(1, stage_launch[dom])
             avg_ms = kernels[dom] / launches

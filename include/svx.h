@@ -109,7 +109,8 @@ int svx_del_penalty(svx_ctx *ctx, const float *scores, int64_t n, double frac, d
 int svx_dense_traceback(svx_ctx *ctx, const int32_t *bp, int s0, int s1, int32_t *align, int32_t *count);
 
 /* sparse_traceback(csum, xp, yp, b_offset, xsize, ysize) -> (alignments, scores)  dp_utils.py:105-143
- * (+ process_scores :89-102).  align [xsize+ysize][4], scores [xsize+ysize] float64, *count as above. */
+ * (+ process_scores :89-102).  align [xsize+ysize+2][4], scores [xsize+ysize+2] float64 (both are also
+ * used as scratch by the walk), *count as above. */
 int svx_sparse_traceback(svx_ctx *ctx, const double *csum, const int32_t *xp, const int32_t *yp,
                          const int32_t *b_offset_out, int a_out, int B, int xsize, int ysize, int32_t *align,
                          double *scores, int32_t *count);
@@ -167,8 +168,11 @@ int svx_align_batch(svx_ctx *ctx, const svx_align_params *params, const svx_pair
 
 /* Device time of the named stage of the last svx_align_batch call, in milliseconds, measured with
  * HIP events on the context's stream when profiling is on (svx_set_profiling); stage names:
- * "pyramid", "knob", "dense", "path", "band_costs", "band_dp", "traceback", "total". -1 if unknown. */
+ * "pyramid", "knob", "dense", "path", "band_costs", "band_dp", "traceback", "total"; "host_plan"/"host_launch" are host wall-clock. -1 if unknown. */
 int svx_set_profiling(svx_ctx *ctx, int on);
+/* Number of internal streams svx_align_batch splits a batch over (1..4, default 1): the serial
+ * kernels of one sub-batch overlap the streaming kernels of the others.  Results do not depend on it. */
+int svx_set_streams(svx_ctx *ctx, int n);
 double svx_stage_ms(svx_ctx *ctx, const char *stage);
 /* Number of launches of the dominant kernel (band_costs) in the last batch, for roofline math. */
 int svx_stage_launches(svx_ctx *ctx, const char *stage);

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
 #include <vector>
 
 #include "svx_common.h"
@@ -22,10 +23,10 @@ int svx_fail(svx_ctx* ctx, int code, const char* fmt, ...) {
 
 static const char* kStageNames[] = {"pyr0",       "pyrN",     "pyr_aux",      "knob_scores",  "knob",      "dense_costs",
                                     "dense_dp",   "path",     "band_costs0",  "band_costsN",  "band_dp0",  "band_dpN",
-                                    "traceback",  "setup",    "total"};
+                                    "traceback",  "setup",    "total",        "host_plan",    "host_launch"};
 enum {
     S_PYR0 = 0, S_PYRN, S_PYR_AUX, S_KNOB_SCORES, S_KNOB, S_DENSE_COSTS, S_DENSE_DP, S_PATH, S_BAND_COSTS0, S_BAND_COSTSN,
-    S_BAND_DP0, S_BAND_DPN, S_TRACEBACK, S_SETUP, S_TOTAL, S_COUNT
+    S_BAND_DP0, S_BAND_DPN, S_TRACEBACK, S_SETUP, S_TOTAL, S_HOST_PLAN, S_HOST_LAUNCH, S_COUNT
 };
 
 struct StageRec {
@@ -38,6 +39,12 @@ struct svx_ctx_ext : svx_ctx {
     int launches[S_COUNT];
     std::vector<StageRec> recs;
     std::vector<SvxPairDev> host;  // descriptors of the last batch (kept alive for the async upload)
+    // sub-batches of one svx_align_batch call run on separate streams so that the latency-bound serial
+    // kernels (DP, traceback) of one sub-batch overlap the streaming kernels of the other
+    int n_streams;
+    hipStream_t aux[3];
+    hipEvent_t fork_ev, join_ev[3];
+    bool aux_ready;
 };
 
 static inline svx_ctx_ext* X(svx_ctx* c) { return static_cast<svx_ctx_ext*>(c); }
@@ -85,6 +92,8 @@ int svx_create(int device_id, svx_ctx** out) {
     c->err[0] = 0;
     c->profiling = 0;
     for (int i = 0; i < S_COUNT; i++) { c->ms[i] = -1.0; c->launches[i] = 0; }
+    c->n_streams = 1;
+    c->aux_ready = false;
     *out = c;
     return SVX_OK;
 }
@@ -94,6 +103,10 @@ int svx_destroy(svx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (X(ctx)->aux_ready) {
+        for (int i = 0; i < 3; i++) { (void)hipStreamDestroy(X(ctx)->aux[i]); (void)hipEventDestroy(X(ctx)->join_ev[i]); }
+        (void)hipEventDestroy(X(ctx)->fork_ev);
+    }
     delete X(ctx);
     return SVX_OK;
 }
@@ -113,6 +126,12 @@ int svx_synchronize(svx_ctx* ctx) {
 const char* svx_last_error(const svx_ctx* ctx) { return ctx ? ctx->err : g_err; }
 
 int64_t svx_scratch_bytes(const svx_ctx* ctx) { return ctx ? (int64_t)ctx->arena_bytes : 0; }
+
+int svx_set_streams(svx_ctx* ctx, int n) {
+    if (!ctx || n < 1 || n > 4) return SVX_ERR_ARG;
+    X(ctx)->n_streams = n;
+    return SVX_OK;
+}
 
 int svx_set_profiling(svx_ctx* ctx, int on) {
     if (!ctx) return SVX_ERR_ARG;
@@ -359,6 +378,7 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const svx_pair* pairs, int n_pairs) {
     NEED(ctx, ctx && prm && (pairs || n_pairs == 0), "svx_align_batch: null argument");
     if (n_pairs <= 0) return SVX_OK;
+    const auto t_enter = std::chrono::steady_clock::now();
     svx_ctx_ext* cx = X(ctx);
     SVX_HIP(ctx, hipSetDevice(ctx->device));
     int rc = check_dim(ctx, prm->d);
@@ -383,7 +403,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
     host.assign(n_pairs, SvxPairDev());
     Bump bump;
     const size_t o_desc = bump.take((size_t)n_pairs * sizeof(SvxPairDev));
-    int maxL = 0, max_ksum = 0, max_kn = 0, max_ds0 = 0, max_ds1 = 0;
+    int maxL = 0, max_ksum = 0, max_kn = 0, max_ds0 = 0, max_ds1 = 0, max_n0 = 0;
     int max_nblk[SVX_MAX_LEVELS] = {0}, max_A[SVX_MAX_LEVELS] = {0};
     bool any_L0 = false;
 #define OFF(ptr_field, bytes) set_off(ptr_field, bump, bytes)
@@ -405,6 +425,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         P.norm_override[1] = in.norms1 != nullptr;
         P.status = in.info + 1;
         if (L > maxL) maxL = L;
+        if (in.n > max_n0) max_n0 = in.n;
         if (L == 0) any_L0 = true;
         if (in.k0 + in.k1 > max_ksum) max_ksum = in.k0 + in.k1;
         const int S_from[2] = {in.k0 > 0 ? ceil_div(prm->num_samps_for_norm, in.k0) : 0,
@@ -450,6 +471,8 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             kidx += 2 * kn;
             if (Lv.kn > max_kn) max_kn = Lv.kn;
             OFF(Lv.kscore, (size_t)kn * sizeof(float));
+            OFF(Lv.korder, (size_t)kn * sizeof(int));
+            OFF(Lv.kstart, (size_t)(Lv.n[0] + 1) * sizeof(int));
             if (in.del_pen) Lv.pen = in.del_pen + l;
             else OFF(Lv.pen, sizeof(double));
             const bool refined = (l < L) || (L == 0);
@@ -507,7 +530,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
                 patch(Lv.P[s]); patch(Lv.part[s]); patch(Lv.mean[s]); patch(Lv.rbar[s]); patch(Lv.inv[s]);
                 if (!(l == 0 && P.norm_override[s])) patch(Lv.nrm[s]);
             }
-            patch(Lv.kscore);
+            patch(Lv.kscore); patch(Lv.korder); patch(Lv.kstart);
             if (!in.del_pen) patch(Lv.pen);
             patch(Lv.path); patch(Lv.path_len); patch(Lv.costs); patch(Lv.boff); patch(Lv.csum); patch(Lv.xp); patch(Lv.yp); patch(Lv.bpk);
             patch(Lv.boff_out);
@@ -518,11 +541,58 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
     }
     SvxPairDev* dpairs = reinterpret_cast<SvxPairDev*>(base + o_desc);
     hipStream_t st = ctx->stream;
+    const auto t_plan = std::chrono::steady_clock::now();
 
     // ---- run
     for (int i = 0; i < S_COUNT; i++) { cx->ms[i] = 0.0; cx->launches[i] = 0; }
     for (auto& r : cx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     cx->recs.clear();
+    auto run_stages = [&](SvxPairDev* dp, int np) -> int {
+        int rc2;
+        for (int l = 0; l <= maxL; l++) {
+            // pyramid: the streaming pass of level l (S_PYR0 / S_PYRN) and its small helpers
+            StageScope sc(ctx, l == 0 ? S_PYR0 : S_PYRN);
+            if ((rc2 = svxl_pyramid_level(ctx, dp, np, l, dtype, d, max_nblk[l], max_ksum, 0))) return rc2;
+        }
+        {
+            StageScope sc(ctx, S_KNOB_SCORES);
+            if ((rc2 = svxl_knob_scores(ctx, dp, np, maxL, max_kn, max_n0, dtype, d))) return rc2;
+        }
+        {
+            StageScope sc(ctx, S_KNOB);
+            if ((rc2 = svxl_del_penalty_batch(ctx, dp, np, maxL + 1, prm->del_percentile_frac))) return rc2;
+        }
+        {
+            StageScope sc(ctx, S_DENSE_COSTS);
+            if ((rc2 = svxl_dense_costs_batch(ctx, dp, np, max_ds0, max_ds1, dtype, d))) return rc2;
+        }
+        {
+            StageScope sc(ctx, S_DENSE_DP);
+            if ((rc2 = svxl_dense_stage_batch(ctx, dp, np, max_ds0))) return rc2;
+        }
+        const int first_depth = maxL > 0 ? maxL - 1 : 0;
+        for (int depth = first_depth; depth >= 0; depth--) {
+            const SvxTypes& ty = depth == 0 ? tfinal : t11;
+            {
+                StageScope sc(ctx, S_PATH);
+                if ((rc2 = svxl_search_path_batch(ctx, dp, np, depth, max_A[depth]))) return rc2;
+            }
+            {
+                StageScope sc(ctx, depth == 0 ? S_BAND_COSTS0 : S_BAND_COSTSN);
+                if ((rc2 = svxl_band_costs_batch(ctx, dp, np, depth, max_A[depth], ty, W, dtype, d))) return rc2;
+            }
+            {
+                StageScope sc(ctx, depth == 0 ? S_BAND_DP0 : S_BAND_DPN);
+                if ((rc2 = svxl_sparse_dp_batch(ctx, dp, np, depth, ty, B))) return rc2;
+            }
+            {
+                StageScope sc(ctx, S_TRACEBACK);
+                if ((rc2 = svxl_sparse_traceback_batch(ctx, dp, np, depth, B, max_A[depth], packable ? 1 : 0))) return rc2;
+            }
+        }
+        return SVX_OK;
+    };
+    (void)any_L0;
     {
         StageScope total(ctx, S_TOTAL);
         {
@@ -538,54 +608,42 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
                             SVX_HIP(ctx, hipMemsetAsync(host[p].lev[l].rbar[s], 0, (size_t)d * sizeof(float), st));
             }
         }
-        for (int l = 0; l <= maxL; l++) {
-            // pyramid: the streaming pass of level l (S_PYR0 / S_PYRN) and its small helpers
-            StageScope sc(ctx, l == 0 ? S_PYR0 : S_PYRN);
-            if ((rc = svxl_pyramid_level(ctx, dpairs, n_pairs, l, dtype, d, max_nblk[l], max_ksum, 0))) return rc;
-        }
-        {
-            StageScope sc(ctx, S_KNOB_SCORES);
-            if ((rc = svxl_knob_scores(ctx, dpairs, n_pairs, maxL, max_kn, dtype, d))) return rc;
-        }
-        {
-            StageScope sc(ctx, S_KNOB);
-            if ((rc = svxl_del_penalty_batch(ctx, dpairs, n_pairs, maxL + 1, prm->del_percentile_frac))) return rc;
-        }
-        {
-            StageScope sc(ctx, S_DENSE_COSTS);
-            if ((rc = svxl_dense_costs_batch(ctx, dpairs, n_pairs, max_ds0, max_ds1, dtype, d))) return rc;
-        }
-        {
-            StageScope sc(ctx, S_DENSE_DP);
-            if ((rc = svxl_dense_stage_batch(ctx, dpairs, n_pairs, max_ds0))) return rc;
-        }
-        (void)any_L0;
-        const int first_depth = maxL > 0 ? maxL - 1 : 0;
-        for (int depth = first_depth; depth >= 0; depth--) {
-            const SvxTypes& ty = depth == 0 ? tfinal : t11;
-            {
-                StageScope sc(ctx, S_PATH);
-                if ((rc = svxl_search_path_batch(ctx, dpairs, n_pairs, depth, max_A[depth]))) return rc;
+        const int S = cx->n_streams < n_pairs ? cx->n_streams : n_pairs;
+        if (S <= 1) {
+            if ((rc = run_stages(dpairs, n_pairs))) return rc;
+        } else {
+            if (!cx->aux_ready) {
+                for (int i = 0; i < 3; i++) {
+                    SVX_HIP(ctx, hipStreamCreateWithFlags(&cx->aux[i], hipStreamNonBlocking));
+                    SVX_HIP(ctx, hipEventCreateWithFlags(&cx->join_ev[i], hipEventDisableTiming));
+                }
+                SVX_HIP(ctx, hipEventCreateWithFlags(&cx->fork_ev, hipEventDisableTiming));
+                cx->aux_ready = true;
             }
-            {
-                StageScope sc(ctx, depth == 0 ? S_BAND_COSTS0 : S_BAND_COSTSN);
-                if ((rc = svxl_band_costs_batch(ctx, dpairs, n_pairs, depth, max_A[depth], ty, W, dtype, d))) return rc;
-            }
-            {
-                StageScope sc(ctx, depth == 0 ? S_BAND_DP0 : S_BAND_DPN);
-                if ((rc = svxl_sparse_dp_batch(ctx, dpairs, n_pairs, depth, ty, B))) return rc;
-            }
-            {
-                StageScope sc(ctx, S_TRACEBACK);
-                if ((rc = svxl_sparse_traceback_batch(ctx, dpairs, n_pairs, depth, B, max_A[depth], packable ? 1 : 0))) return rc;
+            SVX_HIP(ctx, hipEventRecord(cx->fork_ev, st));
+            for (int s2 = 0; s2 < S; s2++) {
+                const int lo = (int)((long long)n_pairs * s2 / S), hi = (int)((long long)n_pairs * (s2 + 1) / S);
+                hipStream_t ss = s2 == 0 ? st : cx->aux[s2 - 1];
+                if (s2 > 0) SVX_HIP(ctx, hipStreamWaitEvent(ss, cx->fork_ev, 0));
+                ctx->stream = ss;
+                rc = run_stages(dpairs + lo, hi - lo);
+                ctx->stream = st;
+                if (rc) return rc;
+                if (s2 > 0) {
+                    SVX_HIP(ctx, hipEventRecord(cx->join_ev[s2 - 1], ss));
+                    SVX_HIP(ctx, hipStreamWaitEvent(st, cx->join_ev[s2 - 1], 0));
+                }
             }
         }
     }
+    const auto t_done = std::chrono::steady_clock::now();
+    cx->ms[S_HOST_PLAN] = std::chrono::duration<double, std::milli>(t_plan - t_enter).count();
+    cx->ms[S_HOST_LAUNCH] = std::chrono::duration<double, std::milli>(t_done - t_plan).count();
     if (ctx->profiling) {
         SVX_HIP(ctx, hipStreamSynchronize(st));
         for (auto& r : cx->recs) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) cx->ms[r.stage] += ms;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) cx->ms[r.stage] += ms;  // (stages of sub-batches overlap)
             (void)hipEventDestroy(r.a);
             (void)hipEventDestroy(r.b);
         }

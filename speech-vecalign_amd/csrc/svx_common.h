@@ -92,6 +92,8 @@ struct SvxLevel {
     int kn;
     int path_cap;
     float* kscore;     // [kn]
+    int* korder;       // [kn] sample ids grouped by source row
+    int* kstart;       // [n0 + 1] first position of each source row in korder
     double* pen;       // deletion penalty of this level
     int* path;         // [path_cap][2]
     int* path_len;
@@ -162,7 +164,7 @@ int svxl_pyramid_level(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int level
 // costs (svx_costs.hip)
 int svxl_score_path(svx_ctx*, const int* xx, const int* yy, int64_t n, const float* n1, const float* n2,
                     const float* v1, int rows1, const float* v2, int rows2, int d, float* out);
-int svxl_knob_scores(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_levels, int max_kn, int dtype, int d);
+int svxl_knob_scores(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_levels, int max_kn, int max_n0, int dtype, int d);
 int svxl_dense_costs(svx_ctx*, const float* v0, int s0, const float* v1, int s1, int d, const float* n0,
                      const float* n1, int mul0, int mul1, float* costs);
 int svxl_dense_costs_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_s0, int max_s1, int dtype, int d);

@@ -26,7 +26,6 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int RS = 144;        // LDS row stride in bytes: 128-byte k-slab + 16 pad (conflict-free b128 reads)
-constexpr int SLAB_BYTES = 128;
 
 template <typename E>
 struct Mma;
@@ -223,35 +222,119 @@ __global__ __launch_bounds__(256) void k_score_path(ScoreArgs g) {
     score_block<E, NCH>(g, (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), (int64_t)gridDim.x * 4);
 }
 
+// Counting sort of one level's knob samples by source row (one workgroup per (level, pair)):
+// korder = sample ids grouped by x, kstart[x] = first position of row x.  max and histogram do not
+// care about sample order, so the scoring kernel may visit the samples row by row and read every
+// source row once instead of once per sample.
+__global__ __launch_bounds__(256) void k_knob_sort(const SvxPairDev* __restrict__ pairs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int part[256];
+    const SvxPairDev& P = pairs[blockIdx.y];
+    const int level = blockIdx.x;
+    if (level > P.L) return;
+    const SvxLevel& Lv = P.lev[level];
+    const int n = Lv.n[0], kn = Lv.kn, tid = threadIdx.x;
+    int* cnt = reinterpret_cast<int*>(smem);  // [n]
+    for (int i = tid; i < n; i += 256) cnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < kn; i += 256) {
+        int x = Lv.kx[i];
+        x = x < 0 ? 0 : (x >= n ? n - 1 : x);
+        atomicAdd(&cnt[x], 1);
+    }
+    __syncthreads();
+    // exclusive scan: each thread owns a contiguous slice
+    const int per = (n + 255) / 256;
+    const int lo = tid * per, hi = (lo + per) < n ? (lo + per) : n;
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += cnt[i];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; i++) { const int v = part[i]; part[i] = run; run += v; }
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int i = lo; i < hi; i++) {
+        const int v = cnt[i];
+        cnt[i] = run;  // becomes the scatter cursor
+        Lv.kstart[i] = run;
+        run += v;
+    }
+    if (tid == 0) Lv.kstart[n] = kn;
+    __syncthreads();
+    for (int i = tid; i < kn; i += 256) {
+        int x = Lv.kx[i];
+        x = x < 0 ? 0 : (x >= n ? n - 1 : x);
+        Lv.korder[atomicAdd(&cnt[x], 1)] = i;
+    }
+}
+
+// One wave per source row x: the row stays in registers while the wave walks the samples (x, y_s).
 // level = blockIdx.y + (LV0 ? 0 : 1)
 template <typename E, int NCH, bool LV0>
 __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restrict__ pairs) {
+    using S = typename E::storage;
+    constexpr int EPL = NCH * E::VEC;
     const SvxPairDev& P = pairs[blockIdx.z];
     const int level = LV0 ? 0 : (int)blockIdx.y + 1;
     if (level > P.L) return;
     const SvxLevel& Lv = P.lev[level];
-    ScoreArgs g;
-    g.v1 = LV0 ? P.v[0] : (const void*)Lv.P[0];
-    g.v2 = LV0 ? P.v[1] : (const void*)Lv.P[1];
-    g.inv1 = LV0 ? Lv.inv[0] : nullptr;
-    g.inv2 = LV0 ? Lv.inv[1] : nullptr;
-    g.n1 = Lv.nrm[0];
-    g.n2 = Lv.nrm[1];
-    g.xx = Lv.kx;
-    g.yy = Lv.ky;
-    g.n = Lv.kn;
-    g.rows1 = Lv.n[0];
-    g.rows2 = Lv.n[1];
-    g.d = P.d;
-    g.out = Lv.kscore;
-    score_block<E, NCH>(g, (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), (int64_t)gridDim.x * 4);
+    const int lane = threadIdx.x & 63;
+    const int n = Lv.n[0], m = Lv.n[1], d = P.d;
+    const S* v1 = LV0 ? reinterpret_cast<const S*>(P.v[0]) : reinterpret_cast<const S*>(Lv.P[0]);
+    const S* v2 = LV0 ? reinterpret_cast<const S*>(P.v[1]) : reinterpret_cast<const S*>(Lv.P[1]);
+    const float* inv1 = LV0 ? Lv.inv[0] : nullptr;
+    const float* inv2 = LV0 ? Lv.inv[1] : nullptr;
+    for (int x = blockIdx.x * 4 + (threadIdx.x >> 6); x < n; x += gridDim.x * 4) {
+        const int s0 = Lv.kstart[x], s1 = Lv.kstart[x + 1];
+        if (s0 >= s1) continue;  // wave-uniform
+        float xr[EPL];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int col = (c * SVX_WAVE + lane) * E::VEC;
+            if (col < d) {
+                load_piece<E>(v1 + (size_t)x * d + col, xr + c * E::VEC);
+            } else {
+#pragma unroll
+                for (int i = 0; i < E::VEC; i++) xr[c * E::VEC + i] = 0.f;
+            }
+        }
+        const float nx = Lv.nrm[0][x];
+        const float ix = LV0 ? inv1[x] : 1.0f;
+        for (int s = s0; s < s1; s++) {
+            const int i = Lv.korder[s];
+            int y = Lv.ky[i];
+            y = y < 0 ? 0 : (y >= m ? m - 1 : y);
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int col = (c * SVX_WAVE + lane) * E::VEC;
+                if (col < d) {
+                    float yr[E::VEC];
+                    load_piece<E>(v2 + (size_t)y * d + col, yr);
+#pragma unroll
+                    for (int k = 0; k < E::VEC; k++) dot += xr[c * E::VEC + k] * yr[k];
+                }
+            }
+            dot = wave_sum(dot);
+            if (lane == 0) {
+                if (LV0) dot = dot * ix * inv2[y];
+                const float den = nx + Lv.nrm[1][y];  // float add, no epsilon (dp_core.pyx:161)
+                Lv.kscore[i] = (float)((2.0 * (1.0 - (double)dot)) / (double)den);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------ band costs
 constexpr int TA = SVX_BC_TA, TB = SVX_BC_TB, ROWS = SVX_BC_ROWS;
 constexpr int BC_THREADS = 512;
-constexpr int TPW = 2;                         // types per wave per pass
-constexpr int TPP = (BC_THREADS / 64) * TPW;   // types per pass
+constexpr int BC_WAVES = BC_THREADS / 64;
+static_assert(BC_WAVES == 8, "the epilogue decodes unit -> (wave, slot) with shifts");
+constexpr int UPW = 6;                        // (type, x-tile) units per wave per pass
+constexpr int TPP = BC_WAVES * UPW / 3;       // types per pass (16)
 
 struct BandArgs {
     const void* v0;  // [k0][n][d]
@@ -273,13 +356,43 @@ __host__ __device__ inline size_t band_smem_bytes(int kx, int ky) {
     size_t hdr = 2 * TA * sizeof(int) + (size_t)(kx + ky) * ROWS * sizeof(char*);
     hdr = (hdr + 15) & ~(size_t)15;
     size_t slab = (size_t)(kx + ky) * ROWS * RS;
-    size_t fs = (size_t)TPP * TA * TB * sizeof(float);
-    return hdr + (slab > fs ? slab : fs);
+    size_t dump = (size_t)BC_WAVES * 16 * ROWS * sizeof(float);
+    return hdr + (slab > dump ? slab : dump);
 }
 
-template <typename E>
+// Global -> register half of the slab staging (issued before the MFMAs of the previous slab so that
+// the HBM/L2 latency hides under them) and register -> LDS half (after the barrier that retires the
+// previous slab's reads).
+template <typename E, int NPT>
+__device__ __forceinline__ void slab_load(uint4* pre, const char* const* rowptr, int npieces, int k0, int d, int tid) {
+    using S = typename E::storage;
+#pragma unroll
+    for (int i = 0; i < NPT; i++) {
+        const int q = tid + i * BC_THREADS;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q < npieces) {
+            const int r = q >> 3, p = q & 7;
+            const char* ptr = rowptr[r];
+            const int kel = k0 + p * E::VEC;
+            if (ptr != nullptr && kel < d) v = *reinterpret_cast<const uint4*>(ptr + (size_t)kel * sizeof(S));
+        }
+        pre[i] = v;
+    }
+}
+template <int NPT>
+__device__ __forceinline__ void slab_store(const uint4* pre, char* slab, int npieces, int tid) {
+#pragma unroll
+    for (int i = 0; i < NPT; i++) {
+        const int q = tid + i * BC_THREADS;
+        if (q < npieces) *reinterpret_cast<uint4*>(slab + (q >> 3) * RS + (q & 7) * 16) = pre[i];
+    }
+}
+
+// NPT = 16-byte pieces a thread stages per k-slab: ceil((kx+ky)*48*8 / 512)
+template <typename E, int NPT>
 __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky, int chunk_a, int chunk_b, char* smem) {
     using S = typename E::storage;
+    using M = Mma<E>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = 2 * g.W;
     const int a0 = chunk_a * TA;
@@ -290,10 +403,10 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
     int* spy = spx + TA;
     const char** rowptr = reinterpret_cast<const char**>(smem + 2 * TA * sizeof(int));
     const int NR = (kx + ky) * ROWS;
+    const int npieces = NR * 8;
     size_t hdr = 2 * TA * sizeof(int) + (size_t)NR * sizeof(char*);
     hdr = (hdr + 15) & ~(size_t)15;
     char* slab = smem + hdr;
-    float* Fs = reinterpret_cast<float*>(slab);  // aliases the slab after the k loop
 
     if (tid < TAe) {
         spx[tid] = g.path[2 * (a0 + tid)];
@@ -309,6 +422,9 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
     const int xlo = spx[0], ylo = spy[0];
     const int X0 = xlo + g.W - (b0 + TBe - 1);
     const int Y0 = ylo - g.W + b0;
+    // rows the chunk's cells actually touch: (x_hi - x_lo) + TBe on the source side, same on the target
+    // side; the remaining staging rows stay zero and cost no global traffic
+    const int NXn = spx[TAe - 1] - xlo + TBe, NYn = spy[TAe - 1] - ylo + TBe;
     for (int r = tid; r < NR; r += BC_THREADS) {
         const int side = r >= kx * ROWS;
         const int rr = side ? r - kx * ROWS : r;
@@ -316,129 +432,143 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
         const int gi = (side ? Y0 : X0) + loc;
         const int nn = side ? g.m : g.n;
         const char* base = reinterpret_cast<const char*>(side ? g.v1 : g.v0);
-        rowptr[r] = (gi >= 0 && gi < nn) ? base + ((size_t)layer * nn + gi) * g.d * sizeof(S) : nullptr;
+        rowptr[r] = (loc < (side ? NYn : NXn) && gi >= 0 && gi < nn) ? base + ((size_t)layer * nn + gi) * g.d * sizeof(S) : nullptr;
     }
+    __syncthreads();
+    const int loff = M::lane_off(lane);
 
     for (int pass = 0; pass * TPP < ty.n; pass++) {
-        const int t0 = pass * TPP + wave * TPW;
-        f32x4_t acc[TPW][9];
+        const int ntp = (ty.n - pass * TPP) < TPP ? (ty.n - pass * TPP) : TPP;
+        const int nunits = ntp * 3;
+        f32x4_t acc[UPW][3];
+        int aoff[UPW], boffs[UPW];  // LDS byte offsets of the unit's x tile rows / its type's y layer
 #pragma unroll
-        for (int ti = 0; ti < TPW; ti++)
+        for (int s = 0; s < UPW; s++) {
 #pragma unroll
-            for (int j = 0; j < 9; j++) acc[ti][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        int xb[TPW], yb[TPW];
-        const int loff = Mma<E>::lane_off(lane);
-#pragma unroll
-        for (int ti = 0; ti < TPW; ti++) {
-            const int t = t0 + ti;
-            xb[ti] = (t < ty.n) ? (ty.x[t] - 1) * ROWS : 0;
-            yb[ti] = (t < ty.n) ? (kx + ty.y[t] - 1) * ROWS : 0;
+            for (int j = 0; j < 3; j++) acc[s][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            const int u = wave + BC_WAVES * s;
+            const int t = pass * TPP + (u < nunits ? u / 3 : 0);
+            const int xt = u % 3;
+            aoff[s] = ((ty.x[t] - 1) * ROWS + xt * 16) * RS + loff;
+            boffs[s] = ((kx + ty.y[t] - 1) * ROWS) * RS + loff;
         }
-        for (int k0 = 0; k0 < g.d; k0 += Mma<E>::KS) {
-            __syncthreads();
-            stage_slab<E>(slab, rowptr, NR, k0, g.d, tid, BC_THREADS);
-            __syncthreads();
+        // k loop, software-pipelined two slabs deep through two register sets: while the MFMAs run on
+        // slab k (in LDS), slab k+1 is already in flight in one set and slab k+2 is being issued into
+        // the other, so every global load has two iterations to land (one block per CU: this is what
+        // keeps enough bytes in flight).
+        uint4 preA[NPT], preB[NPT];
+        const int KS = M::KS;
+        auto mma_slab = [&]() {
 #pragma unroll
-            for (int ti = 0; ti < TPW; ti++) {
-                if (t0 + ti < ty.n) {  // wave-uniform
-                    const char* ap = slab + xb[ti] * RS + loff;
-                    const char* bp = slab + yb[ti] * RS + loff;
+            for (int s = 0; s < UPW; s++) {
+                if (wave + BC_WAVES * s < nunits) {  // wave-uniform
+                    const char* ap = slab + aoff[s];
+                    const char* bp = slab + boffs[s];
 #pragma unroll
-                    for (int ks = 0; ks < Mma<E>::NK; ks++) {
-                        typename Mma<E>::frag fa[3], fb[3];
+                    for (int ks = 0; ks < M::NK; ks++) {
+                        const typename M::frag fa = M::load(ap + ks * M::KSTEP_BYTES);
 #pragma unroll
-                        for (int j = 0; j < 3; j++) {
-                            fa[j] = Mma<E>::load(ap + j * 16 * RS + ks * Mma<E>::KSTEP_BYTES);
-                            fb[j] = Mma<E>::load(bp + j * 16 * RS + ks * Mma<E>::KSTEP_BYTES);
-                        }
-#pragma unroll
-                        for (int xt = 0; xt < 3; xt++)
-#pragma unroll
-                            for (int yt = 0; yt < 3; yt++) Mma<E>::mma(acc[ti][xt * 3 + yt], fa[xt], fb[yt]);
+                        for (int j = 0; j < 3; j++)
+                            M::mma(acc[s][j], fa, M::load(bp + j * 16 * RS + ks * M::KSTEP_BYTES));
                     }
                 }
             }
-        }
-        __syncthreads();  // all waves done reading the slab; Fs may overwrite it
-#pragma unroll
-        for (int ti = 0; ti < TPW; ti++) {
-            const int t = t0 + ti;
-            if (t < ty.n) {
-                const int p = ty.x[t], q = ty.y[t];
-                const float* n0 = g.nrm0 + (size_t)(p - 1) * g.n;
-                const float* n1 = g.nrm1 + (size_t)(q - 1) * g.m;
-                const float* i0 = g.inv0 ? g.inv0 + (size_t)(p - 1) * g.n : nullptr;
-                const float* i1 = g.inv1 ? g.inv1 + (size_t)(q - 1) * g.m : nullptr;
-                float* F = Fs + (size_t)(t - pass * TPP) * TA * TB;
-#pragma unroll
-                for (int xt = 0; xt < 3; xt++)
-#pragma unroll
-                    for (int yt = 0; yt < 3; yt++) {
-                        const int yy = Y0 + yt * 16 + (lane & 15);
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int xx = X0 + xt * 16 + (lane >> 4) * 4 + r;
-                            const int ai = xx + yy - a0;
-                            if (ai >= 0 && ai < TAe) {
-                                const int bi = yy - (spy[ai] - g.W) - b0;
-                                if (bi >= 0 && bi < TBe) {
-                                    float c;
-                                    if (xx >= 0 && xx < g.n && yy >= 0 && yy < g.m) {
-                                        float sumx = acc[ti][xt * 3 + yt][r];
-                                        if (i0) sumx = sumx * i0[xx] * i1[yy];
-                                        c = cost_formula(sumx, p, q, n0[xx], n1[yy]);
-                                    } else {
-                                        c = __builtin_inff();
-                                    }
-                                    F[ai * TB + bi] = c;
-                                }
-                            }
-                        }
-                    }
-            }
-        }
+        };
+        slab_load<E, NPT>(preA, rowptr, npieces, 0, g.d, tid);
+        __syncthreads();  // the previous pass is done with the dump (= slab)
+        slab_store<NPT>(preA, slab, npieces, tid);
+        if (KS < g.d) slab_load<E, NPT>(preA, rowptr, npieces, KS, g.d, tid);
         __syncthreads();
-        // coalesced write-out of the [type][a][b] block
-        const int ntp = (ty.n - pass * TPP) < TPP ? (ty.n - pass * TPP) : TPP;
-        const int per = TAe * TBe;
-        for (int idx = tid; idx < ntp * per; idx += BC_THREADS) {
-            // atb: a-major order so that consecutive threads write consecutive addresses
-            int tl, ai, bi;
-            if (g.atb) {
-                ai = idx / (ntp * TBe);
-                const int rem = idx % (ntp * TBe);
-                tl = rem / TBe;
-                bi = rem % TBe;
-            } else {
-                tl = idx / per;
-                const int rem = idx % per;
-                ai = rem / TBe;
-                bi = rem % TBe;
+        for (int k0 = 0; k0 < g.d; k0 += 2 * KS) {
+            // LDS: slab k0; preA: slab k0+KS (in flight)
+            if (k0 + 2 * KS < g.d) slab_load<E, NPT>(preB, rowptr, npieces, k0 + 2 * KS, g.d, tid);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_slab();
+            __syncthreads();  // every wave has read this slab
+            if (k0 + KS < g.d) {
+                slab_store<NPT>(preA, slab, npieces, tid);
+                __syncthreads();
+                // LDS: slab k0+KS; preB: slab k0+2KS (in flight)
+                if (k0 + 3 * KS < g.d) slab_load<E, NPT>(preA, rowptr, npieces, k0 + 3 * KS, g.d, tid);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_slab();
+                __syncthreads();
+                if (k0 + 2 * KS < g.d) slab_store<NPT>(preB, slab, npieces, tid);
+                __syncthreads();
             }
-            const int t = pass * TPP + tl;
-            const size_t o = g.atb ? ((size_t)(a0 + ai) * ty.n + t) * B + (b0 + bi) : ((size_t)t * g.A + (a0 + ai)) * B + (b0 + bi);
-            g.costs[o] = Fs[((size_t)tl * TA + ai) * TB + bi];
+        }
+        // epilogue, one round per unit slot: every wave dumps the 16 x 48 accumulator block of its
+        // slot-s unit into LDS (aliasing the slab), then all threads walk the chunk's band cells in output
+        // order, pick their dot product out of the dump, apply the cost formula and store coalesced.
+        float* dump = reinterpret_cast<float*>(slab);  // [wave][16][48]
+        const int ncell = TAe * ntp * TBe;
+#pragma unroll
+        for (int s = 0; s < UPW; s++) {
+            if (BC_WAVES * s >= nunits) break;  // block-uniform
+            if (wave + BC_WAVES * s < nunits) {
+                float* dw = dump + wave * (16 * ROWS);
+#pragma unroll
+                for (int yt = 0; yt < 3; yt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) dw[((lane >> 4) * 4 + r) * ROWS + yt * 16 + (lane & 15)] = acc[s][yt][r];
+            }
+            __syncthreads();
+            for (int idx = tid; idx < ncell; idx += BC_THREADS) {
+                // idx -> (a, type, b): a-major like the [A][T][B] layout
+                const int ai = idx / (ntp * TBe);
+                const int rem = idx - ai * (ntp * TBe);
+                const int tl = rem / TBe, bi = rem - tl * TBe;
+                const int yy = spy[ai] - g.W + b0 + bi;
+                const int xx = (a0 + ai) - yy;
+                const int xloc = xx - X0, yloc = yy - Y0;  // 0 <= xloc, yloc < 47 for a unit-step path
+                const int u = tl * 3 + (xloc >> 4);
+                if ((u >> 3) != s || xloc < 0 || xloc >= ROWS || yloc < 0 || yloc >= ROWS) continue;
+                const int t = pass * TPP + tl;
+                const int p = ty.x[t], q = ty.y[t];
+                float c;
+                if (xx >= 0 && xx < g.n && yy >= 0 && yy < g.m) {
+                    float sumx = dump[(u & 7) * (16 * ROWS) + (xloc & 15) * ROWS + yloc];
+                    if (g.inv0) sumx = sumx * g.inv0[(size_t)(p - 1) * g.n + xx] * g.inv1[(size_t)(q - 1) * g.m + yy];
+                    c = cost_formula(sumx, p, q, g.nrm0[(size_t)(p - 1) * g.n + xx], g.nrm1[(size_t)(q - 1) * g.m + yy]);
+                } else {
+                    c = __builtin_inff();
+                }
+                const size_t o = g.atb ? ((size_t)(a0 + ai) * ty.n + t) * B + (b0 + bi) : ((size_t)t * g.A + (a0 + ai)) * B + (b0 + bi);
+                g.costs[o] = c;
+            }
+            __syncthreads();
         }
     }
 }
 
-template <typename E>
+template <typename E, int NPT>
 __global__ __launch_bounds__(BC_THREADS) void k_band_costs(BandArgs g, SvxTypes ty, int kx, int ky, int nchunk_b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    band_block<E>(g, ty, kx, ky, blockIdx.x / nchunk_b, blockIdx.x % nchunk_b, smem);
+    band_block<E, NPT>(g, ty, kx, ky, blockIdx.x / nchunk_b, blockIdx.x % nchunk_b, smem);
 }
 
 // depth 0 uses the final types on the raw rows; deeper levels use (1,1) on normalised fp32 layer 0
-template <typename E, bool LV0>
+// Workgroups are dealt round-robin over the 8 XCDs (id % 8).  Remap the linear id so that each XCD
+// owns one contiguous range of (pair, chunk) work items: neighbouring chunks share up to 2W rows per
+// side, and with this map they share them through the same L2 (speed only, never correctness).
+__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned n) {
+    const unsigned q = n / 8, r = n % 8, xcd = id % 8, k = id / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// depth 0 uses the final types on the raw rows; deeper levels use (1,1) on normalised fp32 layer 0
+template <typename E, bool LV0, int NPT>
 __global__ __launch_bounds__(BC_THREADS) void k_band_costs_batch(const SvxPairDev* __restrict__ pairs, int depth, SvxTypes ty,
-                                                                 int kx, int ky, int W, int nchunk_b) {
+                                                                 int kx, int ky, int W, int nchunk_b, int per_pair) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const SvxPairDev& P = pairs[blockIdx.y];
+    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    const SvxPairDev& P = pairs[wg / per_pair];
+    const int item = wg % per_pair;
     if (depth > P.L || (depth == P.L && P.L > 0)) return;  // refined levels only (or level 0 when L == 0)
     const SvxLevel& Lv = P.lev[depth];
     BandArgs g;
     g.A = *Lv.path_len;
-    const int chunk_a = blockIdx.x / nchunk_b;
+    const int chunk_a = item / nchunk_b;
     if (g.A <= 0 || chunk_a * TA >= g.A) return;
     g.n = Lv.n[0];
     g.m = Lv.n[1];
@@ -455,7 +585,7 @@ __global__ __launch_bounds__(BC_THREADS) void k_band_costs_batch(const SvxPairDe
     g.boff = Lv.boff;
     g.status = P.status;
     g.atb = 1;
-    band_block<E>(g, ty, kx, ky, chunk_a, blockIdx.x % nchunk_b, smem);
+    band_block<E, NPT>(g, ty, kx, ky, chunk_a, item % nchunk_b, smem);
 }
 
 inline int nch_f32(int d) {
@@ -513,11 +643,19 @@ int svxl_score_path(svx_ctx* ctx, const int* xx, const int* yy, int64_t n, const
     return SVX_OK;
 }
 
-int svxl_knob_scores(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int max_L, int max_kn, int dtype, int d) {
+int svxl_knob_scores(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int max_L, int max_kn, int max_n0, int dtype, int d) {
     if (n_pairs <= 0 || max_kn <= 0) return SVX_OK;
-    int nb = (max_kn + 3) / 4;
-    if (nb > 2048) nb = 2048;
     hipStream_t st = ctx->stream;
+    {
+        const size_t smem = (size_t)(max_n0 + 1) * sizeof(int);
+        if (smem > 150 * 1024) return svx_fail(ctx, SVX_ERR_ARG, "knob sort: %d source rows exceed the LDS histogram", max_n0);
+        if (smem > 64 * 1024)
+            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_knob_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(k_knob_sort, dim3(max_L + 1, n_pairs), dim3(256), smem, st, pairs);
+        SVX_LAUNCH_CHECK(ctx, "k_knob_sort");
+    }
+    int nb = (max_n0 + 3) / 4;  // one wave per source row
+    if (nb > 2048) nb = 2048;
 #define M32(N, LV0, GY) hipLaunchKernelGGL((k_knob_scores<ElemF32, N, LV0>), dim3(nb, GY, n_pairs), dim3(256), 0, st, pairs)
 #define M16(E, N) hipLaunchKernelGGL((k_knob_scores<E, N, true>), dim3(nb, 1, n_pairs), dim3(256), 0, st, pairs)
     if (max_L >= 1) {
@@ -583,16 +721,26 @@ int svxl_band_costs(svx_ctx* ctx, const void* v0, int k0, int n, const void* v1,
     const int nca = (A + TA - 1) / TA, ncb = (B + TB - 1) / TB;
     BandArgs g{v0, v1, n, m, d, inv0, inv1, nrm0, nrm1, path, A, W, costs, boff, status, 0};
     dim3 grid((unsigned)(nca * ncb));
-#define LAUNCH(E)                                                                                                   \
+    const int npt = ((kx + ky) * ROWS * 8 + BC_THREADS - 1) / BC_THREADS;
+#define LAUNCH2(E, NPT)                                                                                             \
     do {                                                                                                            \
         if (smem > 64 * 1024)                                                                                       \
-            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_band_costs<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL(k_band_costs<E>, grid, dim3(BC_THREADS), smem, ctx->stream, g, types, kx, ky, ncb);      \
+            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_band_costs<E, NPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_band_costs<E, NPT>), grid, dim3(BC_THREADS), smem, ctx->stream, g, types, kx, ky, ncb); \
     } while (0)
+#define LAUNCH(E)                                                                                                   \
+    do {                                                                                                            \
+        if (npt <= 2) LAUNCH2(E, 2);                                                                                \
+        else if (npt <= 6) LAUNCH2(E, 6);                                                                           \
+        else if (npt <= 8) LAUNCH2(E, 8);                                                                           \
+        else LAUNCH2(E, 14);                                                                                        \
+    } while (0)
+    if (npt > 14) return svx_fail(ctx, SVX_ERR_ARG, "band costs: %d+%d overlap layers exceed the staging limit (18)", kx, ky);
     if (dtype == SVX_F32) LAUNCH(ElemF32);
     else if (dtype == SVX_F16) LAUNCH(ElemF16);
     else LAUNCH(ElemBF16);
 #undef LAUNCH
+#undef LAUNCH2
     SVX_LAUNCH_CHECK(ctx, "k_band_costs");
     return SVX_OK;
 }
@@ -608,18 +756,29 @@ int svxl_band_costs_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, in
     if (smem > 160 * 1024) return svx_fail(ctx, SVX_ERR_ARG, "band costs: %d+%d overlap layers need %zu bytes of LDS (>160 KiB)", kx, ky, smem);
     const int B = 2 * W;
     const int nca = (max_A + TA - 1) / TA, ncb = (B + TB - 1) / TB;
-    dim3 grid((unsigned)(nca * ncb), n_pairs);
-#define LAUNCH(E, LV0)                                                                                              \
+    const int per_pair = nca * ncb;
+    dim3 grid((unsigned)per_pair * (unsigned)n_pairs);
+    const int npt = ((kx + ky) * ROWS * 8 + BC_THREADS - 1) / BC_THREADS;
+#define LAUNCH2(E, LV0, NPT)                                                                                        \
     do {                                                                                                            \
         if (smem > 64 * 1024)                                                                                       \
-            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_band_costs_batch<E, LV0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL((k_band_costs_batch<E, LV0>), grid, dim3(BC_THREADS), smem, ctx->stream, pairs, depth, types, kx, ky, W, ncb); \
+            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_band_costs_batch<E, LV0, NPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_band_costs_batch<E, LV0, NPT>), grid, dim3(BC_THREADS), smem, ctx->stream, pairs, depth, types, kx, ky, W, ncb, per_pair); \
     } while (0)
+#define LAUNCH(E, LV0)                                                                                              \
+    do {                                                                                                            \
+        if (npt <= 2) LAUNCH2(E, LV0, 2);                                                                           \
+        else if (npt <= 6) LAUNCH2(E, LV0, 6);                                                                      \
+        else if (npt <= 8) LAUNCH2(E, LV0, 8);                                                                      \
+        else LAUNCH2(E, LV0, 14);                                                                                   \
+    } while (0)
+    if (npt > 14) return svx_fail(ctx, SVX_ERR_ARG, "band costs: %d+%d overlap layers exceed the staging limit (18)", kx, ky);
     if (depth > 0) LAUNCH(ElemF32, false);
     else if (dtype == SVX_F32) LAUNCH(ElemF32, true);
     else if (dtype == SVX_F16) LAUNCH(ElemF16, true);
     else LAUNCH(ElemBF16, true);
 #undef LAUNCH
+#undef LAUNCH2
     SVX_LAUNCH_CHECK(ctx, "k_band_costs_batch");
     return SVX_OK;
 }

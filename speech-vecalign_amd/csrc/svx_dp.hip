@@ -266,15 +266,38 @@ __device__ __forceinline__ void dpf_stage(const SparseDpArgs& g, const int* tpk,
     }
 }
 
+// Exchange with lane ^ 16 / lane ^ 32 through the gfx950 permlane swaps (VALU, no LDS round trip).
+__device__ __forceinline__ unsigned xchg16_u32(unsigned v, int lane) {
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return ((lane >> 4) & 1) ? r[0] : r[1];
+}
+__device__ __forceinline__ unsigned xchg32_u32(unsigned v, int lane) {
+    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (lane & 32) ? r[0] : r[1];
+}
+__device__ __forceinline__ double xchg16_f64(double v, int lane) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = xchg16_u32((unsigned)u, lane), hi = xchg16_u32((unsigned)(u >> 32), lane);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double xchg32_f64(double v, int lane) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = xchg32_u32((unsigned)u, lane), hi = xchg32_u32((unsigned)(u >> 32), lane);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
 // G lane groups of LB = 64/G lanes share one diagonal: lane = grp*LB + b, group grp relaxes the
 // transitions t = grp, grp+G, ...; the per-group winners are merged by (total, t) so that the
 // reference's "first strictly smaller candidate wins" order is preserved exactly.
+template <int TPLT>
 __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH, char* smem) {
+    constexpr int DPF_TPL = TPLT > 0 ? TPLT : 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int A = g.A, B = g.B, Aout = A + 2, T = ty.n, NTt = ty.n + 2, RD = ty.maxstep + 1;
     const int G = B <= 16 ? 4 : (B <= 32 ? 2 : 1);
     const int LB = 64 / G;
     const int b = lane & (LB - 1), grp = lane / LB;
+    constexpr bool pipelined = TPLT > 0;  // the launcher picks TPLT = ceil((T+2)/G) when it is <= 6
     double* ring = reinterpret_cast<double*>(smem);
     int* tpk = reinterpret_cast<int*>(ring + (size_t)RD * B);
     int* bo_buf = tpk + (SVX_MAX_TYPES + 2);
@@ -299,6 +322,87 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
             const int* bo = bo_buf + (size_t)(c & 1) * CH;
             const int* sh = sh_buf + (size_t)(c & 1) * CH * NTt;
             const int a_end = (a0 + CH) < Aout ? (a0 + CH) : Aout;
+            if (pipelined) {
+                // Software-pipelined sweep: everything of diagonal a+1 that does not depend on csum (band
+                // offsets, lane shifts, ring addresses, costs) is prepared between issuing the ring reads
+                // of diagonal a and consuming them, so the serial chain is ring read -> add/compare ->
+                // group merge -> ring write.
+                int ridx[DPF_TPL], key[DPF_TPL];
+                double cst[DPF_TPL];
+                unsigned okm = 0;
+                int yy = 0, xx = 0;
+                auto prep = [&](int a, int sl, int* r_, int* k_, double* c_, unsigned& ok_, int& yy_, int& xx_) {
+                    const int i = a - a0;
+                    yy_ = b + bo[i];
+                    xx_ = a - yy_;
+                    const bool general = (b < B) && 1 <= xx_ && xx_ <= g.xs && 1 <= yy_ && yy_ <= g.ys && a - 2 < A;
+                    const float* crow = cb + i * TB + b;
+                    const int* shr = sh + i * NTt;
+                    ok_ = 0;
+#pragma unroll
+                    for (int j = 0; j < DPF_TPL; j++) {
+                        const int t = grp + G * j;
+                        const int tc = t < NTt ? t : NTt - 1;
+                        const int pk = tpk[tc];
+                        const int xo = pk & 255, yo = (pk >> 8) & 255, st = pk >> 16;
+                        const int bpv = b + shr[tc];
+                        const bool ok = general && t < NTt && xo <= xx_ && yo <= yy_ && 0 <= bpv && bpv < B;
+                        int ps = sl - st;
+                        ps = ps < 0 ? ps + RD : ps;
+                        r_[j] = ps * B + (ok ? bpv : 0);
+                        k_[j] = (t << 16) | (pk & 0xffff);  // ordered by t; carries (xo, yo) through the merge
+                        c_[j] = (tc >= T) ? pen : (double)crow[tc * B];
+                        ok_ |= ok ? (1u << j) : 0u;
+                    }
+                };
+                prep(a0, slot, ridx, key, cst, okm, yy, xx);
+                for (int a = a0; a < a_end; a++) {
+                    double pv[DPF_TPL];
+#pragma unroll
+                    for (int j = 0; j < DPF_TPL; j++) pv[j] = ring[ridx[j]];
+                    const int cyy = yy, cxx = xx;
+                    const unsigned cok = okm;
+                    double ccst[DPF_TPL];
+                    int ckey[DPF_TPL];
+#pragma unroll
+                    for (int j = 0; j < DPF_TPL; j++) { ccst[j] = cst[j]; ckey[j] = key[j]; }
+                    const int nslot = (slot + 1 == RD) ? 0 : slot + 1;
+                    if (a + 1 < a_end) prep(a + 1, nslot, ridx, key, cst, okm, yy, xx);
+                    double best = inf;
+                    int bk = 0x7fffffff;
+#pragma unroll
+                    for (int j = 0; j < DPF_TPL; j++) {
+                        const double tot = pv[j] + ccst[j];
+                        if (((cok >> j) & 1u) && tot < best) { best = tot; bk = ckey[j]; }
+                    }
+                    if (G == 4) {
+                        const double ob = xchg16_f64(best, lane);
+                        const int ok2 = (int)xchg16_u32((unsigned)bk, lane);
+                        if (ob < best || (ob == best && ok2 < bk)) { best = ob; bk = ok2; }
+                    }
+                    if (G >= 2) {
+                        const double ob = xchg32_f64(best, lane);
+                        const int ok2 = (int)xchg32_u32((unsigned)bk, lane);
+                        if (ob < best || (ob == best && ok2 < bk)) { best = ob; bk = ok2; }
+                    }
+                    if (b < B && grp == 0) {
+                        int bx, by;
+                        if (cxx == 0 && 0 <= cyy && cyy <= g.ys) {
+                            best = pen * (double)cyy; bx = 0; by = 1;
+                        } else if (cyy == 0 && 0 <= cxx && cxx <= g.xs) {
+                            best = pen * (double)cxx; bx = 1; by = 0;
+                        } else if (bk != 0x7fffffff) {
+                            bx = bk & 255; by = (bk >> 8) & 255;
+                        } else {
+                            best = inf; bx = -42; by = -42;
+                        }
+                        ring[slot * B + b] = best;
+                        store_node(g, (size_t)((unsigned)a * (unsigned)B + (unsigned)b), best, bx, by);
+                    }
+                    slot = nslot;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else
             for (int a = a0; a < a_end; a++) {
                 const int i = a - a0;
                 const bool active = b < B;
@@ -309,8 +413,8 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
                 // general node: cost cell (a-2, b) exists (b_offset_out[a] = b_offset_in[a-2] + 1, so bc == b)
                 const bool general = active && 1 <= xx && xx <= g.xs && 1 <= yy && yy <= g.ys && a - 2 < A;
                 if (general) {
-                    const float* crow = cb + (size_t)i * TB + b;
-                    const int* shr = sh + (size_t)i * NTt;
+                    const float* crow = cb + i * TB + b;
+                    const int* shr = sh + i * NTt;
                     for (int t = grp; t < NTt; t += G) {
                         const int pk = tpk[t];
                         const int xo = pk & 255, yo = (pk >> 8) & 255, st = pk >> 16;
@@ -318,16 +422,21 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
                         const bool ok = xo <= xx && yo <= yy && 0 <= bpv && bpv < B;
                         int ps = slot - st;
                         ps = ps < 0 ? ps + RD : ps;
-                        const double prev = ring[(size_t)ps * B + (ok ? bpv : 0)];
+                        const double prev = ring[ps * B + (ok ? bpv : 0)];
                         const double ac_cost = (t >= T) ? pen : (double)crow[t * B];
                         const double tot = prev + ac_cost;
                         if (ok && tot < best) { best = tot; bt = t; }
                     }
                 }
                 // merge the groups: smaller total wins, equal totals -> smaller transition index
-                for (int m = LB; m < 64; m <<= 1) {
-                    const double ob = __shfl_xor(best, m, 64);
-                    const int ot = __shfl_xor(bt, m, 64);
+                if (G == 4) {
+                    const double ob = xchg16_f64(best, lane);
+                    const int ot = (int)xchg16_u32((unsigned)bt, lane);
+                    if (ob < best || (ob == best && ot < bt)) { best = ob; bt = ot; }
+                }
+                if (G >= 2) {
+                    const double ob = xchg32_f64(best, lane);
+                    const int ot = (int)xchg32_u32((unsigned)bt, lane);
                     if (ob < best || (ob == best && ot < bt)) { best = ob; bt = ot; }
                 }
                 if (active && grp == 0) {
@@ -342,8 +451,8 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
                     } else {
                         best = inf; bx = -42; by = -42;
                     }
-                    ring[(size_t)slot * B + b] = best;
-                    store_node(g, (size_t)a * B + b, best, bx, by);
+                    ring[slot * B + b] = best;
+                    store_node(g, (size_t)((unsigned)a * (unsigned)B + (unsigned)b), best, bx, by);
                 }
                 slot = (slot + 1 == RD) ? 0 : slot + 1;
                 __builtin_amdgcn_wave_barrier();
@@ -359,9 +468,10 @@ __global__ __launch_bounds__(1024) void k_sparse_dp(SparseDpArgs g, SvxTypes ty)
     sparse_dp_block<RING>(g, ty, reinterpret_cast<double*>(smem));
 }
 
+template <int TPLT>
 __global__ __launch_bounds__(DPF_THREADS) void k_sparse_dp_fast(SparseDpArgs g, SvxTypes ty, int CH) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    sparse_dp_fast(g, ty, CH, smem);
+    sparse_dp_fast<TPLT>(g, ty, CH, smem);
 }
 
 __device__ __forceinline__ bool batch_dp_args(const SvxPairDev& P, int depth, int B, SparseDpArgs* g) {
@@ -393,12 +503,13 @@ __global__ __launch_bounds__(1024) void k_sparse_dp_batch(const SvxPairDev* __re
     sparse_dp_block<RING>(g, ty, reinterpret_cast<double*>(smem));
 }
 
+template <int TPLT>
 __global__ __launch_bounds__(DPF_THREADS) void k_sparse_dp_fast_batch(const SvxPairDev* __restrict__ pairs, int depth,
                                                                        SvxTypes ty, int B, int CH) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SparseDpArgs g;
     if (!batch_dp_args(pairs[blockIdx.x], depth, B, &g)) return;
-    sparse_dp_fast(g, ty, CH, smem);
+    sparse_dp_fast<TPLT>(g, ty, CH, smem);
 }
 
 // ------------------------------------------------------------------------------ band traceback
@@ -421,22 +532,34 @@ struct TbArgs {
     int use_lds;               // LDS holds boff [Aout] ints, then bp [Aout*B]: bytes (from bpk) or 16-bit (from xp/yp)
 };
 
+__host__ __device__ inline size_t tb_bp_bytes(int Aout, int B, bool wide) {
+    return (((size_t)Aout * B * (wide ? 2 : 1)) + 15) & ~(size_t)15;
+}
 __host__ __device__ inline size_t tb_smem_bytes(int Aout, int B, bool wide) {
-    return (size_t)Aout * sizeof(int) + (size_t)Aout * B * (wide ? 2 : 1);
+    return tb_bp_bytes(Aout, B, wide) + (size_t)Aout * sizeof(int);  // back-pointers first (16-byte aligned), then boff
 }
 
 __device__ void sparse_traceback_block(const TbArgs& g, char* smem) {
     __shared__ int sh_n;
     const int cap = g.xs + g.ys + 2;
     const int Aout = g.Aout, B = g.B;
-    int* lbo = reinterpret_cast<int*>(smem);
-    unsigned char* lbp = reinterpret_cast<unsigned char*>(smem) + (size_t)Aout * sizeof(int);
+    unsigned char* lbp = reinterpret_cast<unsigned char*>(smem);
     unsigned short* lbw = reinterpret_cast<unsigned short*>(lbp);
+    int* lbo = reinterpret_cast<int*>(smem + tb_bp_bytes(Aout, B, g.bpk == nullptr));
     if (g.use_lds) {
         for (int i = threadIdx.x; i < Aout; i += blockDim.x) lbo[i] = g.boff[i];
         const size_t nb = (size_t)Aout * B;
         if (g.bpk) {
-            for (size_t i = threadIdx.x; i < nb; i += blockDim.x) lbp[i] = g.bpk[i];
+            // 16-byte copies (the arena keeps bpk 256-byte aligned; the LDS copy starts at offset 0)
+            const size_t nv = nb / 16;
+            if ((reinterpret_cast<size_t>(g.bpk) & 15) == 0) {
+                const uint4* src = reinterpret_cast<const uint4*>(g.bpk);
+                uint4* dst = reinterpret_cast<uint4*>(lbp);
+                for (size_t i = threadIdx.x; i < nv; i += blockDim.x) dst[i] = src[i];
+                for (size_t i = nv * 16 + threadIdx.x; i < nb; i += blockDim.x) lbp[i] = g.bpk[i];
+            } else {
+                for (size_t i = threadIdx.x; i < nb; i += blockDim.x) lbp[i] = g.bpk[i];
+            }
         } else {
             for (size_t i = threadIdx.x; i < nb; i += blockDim.x) {
                 const int px = g.xp[i], py = g.yp[i];
@@ -848,6 +971,13 @@ int svxl_dense_traceback(svx_ctx* ctx, const int* bp, int s0, int s1, int* align
     return SVX_OK;
 }
 
+// transitions per lane of the pipelined sweep: ceil((T+2)/G) rounded up to an instantiated size, 0 = generic loop
+static int dpf_tpl(int T, int B) {
+    const int G = B <= 16 ? 4 : (B <= 32 ? 2 : 1);
+    const int t = (T + 2 + G - 1) / G;
+    return t <= 4 ? t : (t <= 6 ? 6 : 0);
+}
+
 static int dpf_choose_ch(int T, int B, int maxstep) {
     if (B > 64 || maxstep > 120) return 0;  // transitions are packed into 8-bit fields
     const int opts[4] = {64, 32, 16, 8};
@@ -863,9 +993,21 @@ int svxl_sparse_dp(svx_ctx* ctx, const float* costs, const int* boff_in, int A, 
     const int CH = dpf_choose_ch(types.n, B, types.maxstep);
     if (CH > 0) {
         const size_t smem = dpf_smem_bytes(types.n, B, types.maxstep + 1, CH);
-        if (smem > 64 * 1024)
-            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_dp_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(k_sparse_dp_fast, dim3(1), dim3(DPF_THREADS), smem, ctx->stream, g, types, CH);
+#define DPF_LAUNCH(TPLT)                                                                                              \
+    do {                                                                                                              \
+        if (smem > 64 * 1024)                                                                                         \
+            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_dp_fast<TPLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL(k_sparse_dp_fast<TPLT>, dim3(1), dim3(DPF_THREADS), smem, ctx->stream, g, types, CH);      \
+    } while (0)
+        switch (dpf_tpl(types.n, B)) {
+            case 1: DPF_LAUNCH(1); break;
+            case 2: DPF_LAUNCH(2); break;
+            case 3: DPF_LAUNCH(3); break;
+            case 4: DPF_LAUNCH(4); break;
+            case 6: DPF_LAUNCH(6); break;
+            default: DPF_LAUNCH(0); break;
+        }
+#undef DPF_LAUNCH
         SVX_LAUNCH_CHECK(ctx, "k_sparse_dp_fast");
         return SVX_OK;
     }
@@ -887,9 +1029,21 @@ int svxl_sparse_dp_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int
     const int CH = dpf_choose_ch(types.n, B, types.maxstep);
     if (CH > 0) {
         const size_t smem = dpf_smem_bytes(types.n, B, types.maxstep + 1, CH);
-        if (smem > 64 * 1024)
-            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_dp_fast_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(k_sparse_dp_fast_batch, dim3(n_pairs), dim3(DPF_THREADS), smem, ctx->stream, pairs, depth, types, B, CH);
+#define DPF_LAUNCH(TPLT)                                                                                              \
+    do {                                                                                                              \
+        if (smem > 64 * 1024)                                                                                         \
+            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_dp_fast_batch<TPLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL(k_sparse_dp_fast_batch<TPLT>, dim3(n_pairs), dim3(DPF_THREADS), smem, ctx->stream, pairs, depth, types, B, CH); \
+    } while (0)
+        switch (dpf_tpl(types.n, B)) {
+            case 1: DPF_LAUNCH(1); break;
+            case 2: DPF_LAUNCH(2); break;
+            case 3: DPF_LAUNCH(3); break;
+            case 4: DPF_LAUNCH(4); break;
+            case 6: DPF_LAUNCH(6); break;
+            default: DPF_LAUNCH(0); break;
+        }
+#undef DPF_LAUNCH
         SVX_LAUNCH_CHECK(ctx, "k_sparse_dp_fast_batch");
         return SVX_OK;
     }

@@ -75,6 +75,7 @@ _SIGS = {
     "svx_knob_count": (c_i64, [c_int, c_int, c_int]),
     "svx_align_batch": (c_int, [c_vp, ctypes.POINTER(AlignParams), ctypes.POINTER(Pair), c_int]),
     "svx_set_profiling": (c_int, [c_vp, c_int]),
+    "svx_set_streams": (c_int, [c_vp, c_int]),
     "svx_stage_ms": (c_f64, [c_vp, ctypes.c_char_p]),
     "svx_stage_launches": (c_int, [c_vp, ctypes.c_char_p]),
 }

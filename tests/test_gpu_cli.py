@@ -1,0 +1,76 @@
+"""End-to-end on the GPU through the reference's command line (svx.seg_align.align): the trimmed
+prefix of the reference's shipped example (tests/golden/example_trim, real SONAR/SpeechLASER fp16
+embeddings) must reproduce the REAL reference's alignment file for np.random.seed(0):
+identical spans, scores within 1e-4."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TRIM = os.path.join(os.path.dirname(__file__), "golden", "example_trim")
+
+
+def build_tree(root, stopes=False, copies=1):
+    meta = []
+    for c in range(copies):
+        stem = "doc%d" % c
+        for lang in ("en", "de"):
+            for sub in ("seg", "cat", "emb"):
+                os.makedirs(os.path.join(root, sub, lang), exist_ok=True)
+            shutil.copy(os.path.join(TRIM, f"segments_{lang}.txt"), os.path.join(root, "seg", lang, f"{stem}_{lang}.txt"))
+            shutil.copy(os.path.join(TRIM, f"cat_segs_{lang}.txt"), os.path.join(root, "cat", lang, f"{stem}_{lang}.txt"))
+            dst = os.path.join(root, "emb", lang, f"{stem}_{lang}.embed")
+            if stopes:  # stopes' Embedding files are .npy v1.0 with an .embed suffix
+                arr = np.fromfile(os.path.join(TRIM, f"embeds_{lang}.f16"), dtype=np.float16).reshape(-1, 1024)
+                np.save(dst + ".npy", arr)
+                os.rename(dst + ".npy", dst)
+            else:
+                shutil.copy(os.path.join(TRIM, f"embeds_{lang}.f16"), dst)
+        os.makedirs(os.path.join(root, "ign", "en-de"), exist_ok=True)
+        for side in ("src", "tgt"):
+            shutil.copy(os.path.join(TRIM, f"ignore_{side}.txt"), os.path.join(root, "ign", "en-de", f"{stem}_en-{stem}_de.{side}.txt"))
+        meta.append(f"/audio/{stem}_en.ogg\t/audio/{stem}_de.ogg")
+    with open(os.path.join(root, "metadata.tsv"), "w") as f:
+        f.write("\n".join(meta) + "\n")
+
+
+def run_cli(root, out, extra):
+    from svx.seg_align import align as A
+    A.main([os.path.join(root, "metadata.tsv"), out, "--src_lang", "en", "--tgt_lang", "de", "--seg_dir", os.path.join(root, "seg"),
+            "--concat_dir", os.path.join(root, "cat"), "--embed_dir", os.path.join(root, "emb"),
+            "--ign_indices_dir", os.path.join(root, "ign")] + extra)
+
+
+def parse(path):
+    from svx.utils.file_utils import read_alignments_with_score
+    return read_alignments_with_score(path)
+
+
+@pytest.mark.parametrize("stopes", [False, True])
+def test_trimmed_example_matches_reference_output(tmp_path, stopes):
+    root = str(tmp_path / "data")
+    build_tree(root, stopes=stopes)
+    out = str(tmp_path / "out")
+    np.random.seed(0)
+    run_cli(root, out, ["--is_stopes_embed"] if stopes else ["--fp16_embed"])
+    got = parse(os.path.join(out, "en-de", "doc0_en-doc0_de.txt"))
+    want = parse(os.path.join(TRIM, "expected_seed0.txt"))
+    assert [(a, b) for a, b, _ in got] == [(a, b) for a, b, _ in want]
+    assert max(abs(g[2] - w[2]) for g, w in zip(got, want)) < 1e-4 + 5e-7  # file has 6 decimals
+
+
+def test_seeded_runs_are_batch_invariant(tmp_path):
+    root = str(tmp_path / "data")
+    build_tree(root, copies=3)
+    outs = []
+    for i, bs in enumerate((1, 3)):
+        out = str(tmp_path / ("out%d" % i))
+        run_cli(root, out, ["--fp16_embed", "--seed", "11", "--batch_size", str(bs)])
+        outs.append([open(os.path.join(out, "en-de", f"doc{c}_en-doc{c}_de.txt")).read() for c in range(3)])
+    assert outs[0] == outs[1]
+    # --skip_existing leaves finished outputs alone
+    stamp = os.path.getmtime(os.path.join(str(tmp_path / "out1"), "en-de", "doc0_en-doc0_de.txt"))
+    run_cli(root, str(tmp_path / "out1"), ["--fp16_embed", "--seed", "11", "--skip_existing"])
+    assert os.path.getmtime(os.path.join(str(tmp_path / "out1"), "en-de", "doc0_en-doc0_de.txt")) == stamp

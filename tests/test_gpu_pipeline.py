@@ -93,6 +93,25 @@ def test_batch_invariance_and_idempotence():
         assert xs == list(range(shapes[i][0])) and ys == list(range(shapes[i][1]))
 
 
+def test_stream_count_does_not_change_results():
+    """svx_set_streams only changes how sub-batches overlap in time."""
+    from svx import _lib
+    from svx.vecalign import dp_utils
+    types = alignment_types(4)
+    docs = [make_pair(500 + 37 * i, 520 - 11 * i, 3, 64, 60 + i) for i in range(5)]
+    ctx = _lib.context()
+    outs = []
+    try:
+        for ns in (1, 2, 4):
+            ctx.lib.svx_set_streams(ctx.h, ns)
+            outs.append(dp_utils.align_batch(docs, types, 0.2, 7, 300, 20000, 100, rngs=[np.random.RandomState(i) for i in range(5)]))
+    finally:
+        ctx.lib.svx_set_streams(ctx.h, 1)
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
 def test_norm_overrides_and_global_stream(orc):
     """norms0/norms1 overrides (dp_utils.py:428-444) skip the corresponding random draws."""
     from svx.vecalign import dp_utils

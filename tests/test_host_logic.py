@@ -204,3 +204,39 @@ def test_draw_indices_layout():
     assert len(ni2) == len(ni) - 3 * 34
     _, ks = dp_utils.draw_indices(90, 80, 2, 2, 300, 20000, 100, rng=np.random.RandomState(1))
     assert len(ks) == 2 * 7200 and np.array_equal(ks[:80], np.zeros(80)) and np.array_equal(ks[7200:7280], np.arange(80))
+
+
+def test_concat_segs_and_untranslated_fixture(tmp_path):
+    """Candidate enumeration on the trimmed example: every line of the fixture's cat_segs file is
+    produced (the fixture is a prefix cut of the reference's own output), in string-sorted order."""
+    from svx.seg_align import concat_segs as C
+    from svx.seg_align import detect_untranslate_concats as D
+    seg = os.path.join(TRIM, "segments_en.txt")
+    lines = sorted(C.get_overlaps(seg, 5, int(20.0 * C.SAMPLE_RATE)))
+    want = open(os.path.join(TRIM, "cat_segs_en.txt")).read().splitlines()
+    assert want == sorted(want) and set(want) <= set(lines)
+    C.overlap(seg, tmp_path / "x" / "o.txt", 5, max_dur=20.0)
+    assert (tmp_path / "x" / "o.txt").read_text().splitlines() == lines
+    segs = [(0, 10), (10, 20), (20, 400000), (400000, 400010), (400010, 400020)]
+    assert list(C.candidate_windows(segs, 3, 320000)) == [(0, 0), (0, 1), (1, 1), (3, 3), (3, 4), (4, 4)]
+    (tmp_path / "segs.txt").write_text("".join(f"{a} {b}\n" for a, b in segs))
+    (tmp_path / "ident.txt").write_text("1\n4\n")
+    assert D.get_identical_overlap_ids(tmp_path / "segs.txt", 3, 320000, tmp_path / "ident.txt") == [(0, 1), (1, 1), (3, 4), (4, 4)]
+
+
+@needs_ref
+def test_concat_segs_and_untranslated_match_shipped_example(tmp_path):
+    """Byte-exact regeneration of example/voxpopuli/cat_segs and untrans_cat_seg_ids."""
+    from svx.seg_align import concat_segs as C
+    from svx.seg_align import detect_untranslate_concats as D
+    ref = ref_loader.load()
+    ex = os.path.join(ref.root, "example", "voxpopuli")
+    stem = "20180313-0900-PLENARY-15"
+    for lang, side in (("en", "src"), ("de", "tgt")):
+        seg = os.path.join(ex, "segments", lang, f"{stem}_{lang}.txt")
+        C.overlap(seg, tmp_path / f"{lang}.txt", 5, max_dur=20.0)
+        assert (tmp_path / f"{lang}.txt").read_text() == open(os.path.join(ex, "cat_segs", lang, f"{stem}_{lang}.txt")).read()
+        got = D.get_identical_overlap_ids(seg, 5, int(20.0 * C.SAMPLE_RATE),
+                                          os.path.join(ex, "untrans_segs", "en-de", f"{stem}_en-{stem}_de.{side}.txt"))
+        want = open(os.path.join(ex, "untrans_cat_seg_ids", "en-de", f"{stem}_en-{stem}_de.{side}.txt")).read()
+        assert "".join(f"{i} {j}\n" for i, j in got) == want
