@@ -332,9 +332,10 @@ __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restric
 constexpr int TA = SVX_BC_TA, TB = SVX_BC_TB, ROWS = SVX_BC_ROWS;
 constexpr int BC_THREADS = 512;
 constexpr int BC_WAVES = BC_THREADS / 64;
-static_assert(BC_WAVES == 8, "the epilogue decodes unit -> (wave, slot) with shifts");
+static_assert(BC_WAVES == 8, "unit -> (wave, slot) is decoded with shifts");
 constexpr int UPW = 6;                        // (type, x-tile) units per wave per pass
 constexpr int TPP = BC_WAVES * UPW / 3;       // types per pass (16)
+constexpr int DUMP_UNIT = 16 * ROWS;          // floats of one unit's 16 x 48 accumulator block
 
 struct BandArgs {
     const void* v0;  // [k0][n][d]
@@ -352,26 +353,41 @@ struct BandArgs {
     int atb;
 };
 
-__host__ __device__ inline size_t band_smem_bytes(int kx, int ky) {
-    size_t hdr = 2 * TA * sizeof(int) + (size_t)(kx + ky) * ROWS * sizeof(char*);
-    hdr = (hdr + 15) & ~(size_t)15;
-    size_t slab = (size_t)(kx + ky) * ROWS * RS;
-    size_t dump = (size_t)BC_WAVES * 16 * ROWS * sizeof(float);
-    return hdr + (slab > dump ? slab : dump);
+// LDS map of a band workgroup: [header: path chunk, types, row pointers, per-row scalars][work area].
+// The work area holds the k-slab rows during the k loop and, afterwards, the accumulator dump and
+// the output block Fs.  SW = slab width in 128-byte units (1 or 2).
+struct BandLds {
+    size_t off_rowptr, off_scal, off_work, work_bytes, total;
+    int rs;  // slab row stride in bytes
+};
+__host__ __device__ inline BandLds band_lds(int kx, int ky, int sw, int ntypes_pass) {
+    BandLds L;
+    const int NR = (kx + ky) * ROWS;
+    size_t o = (2 * TA + 2 * (SVX_MAX_TYPES + 2)) * sizeof(int);  // spx, spy, tx, ty
+    L.off_rowptr = (o + 15) & ~(size_t)15;
+    o = L.off_rowptr + (size_t)NR * sizeof(char*);
+    L.off_scal = (o + 15) & ~(size_t)15;
+    o = L.off_scal + 2 * (size_t)NR * sizeof(float);  // normaliser and inverse norm per staged row
+    L.off_work = (o + 15) & ~(size_t)15;
+    L.rs = sw * 128 + 16;
+    const size_t slab = (size_t)NR * L.rs;
+    const size_t fs = (size_t)ntypes_pass * TA * TB * sizeof(float);
+    const size_t epi = fs + (size_t)BC_WAVES * DUMP_UNIT * sizeof(float);  // Fs + at least one dump round
+    L.work_bytes = slab > epi ? slab : epi;
+    L.total = L.off_work + L.work_bytes;
+    return L;
 }
 
-// Global -> register half of the slab staging (issued before the MFMAs of the previous slab so that
-// the HBM/L2 latency hides under them) and register -> LDS half (after the barrier that retires the
-// previous slab's reads).
-template <typename E, int NPT>
+template <typename E, int NPT, int SW>
 __device__ __forceinline__ void slab_load(uint4* pre, const char* const* rowptr, int npieces, int k0, int d, int tid) {
     using S = typename E::storage;
+    constexpr int PPR = 8 * SW;  // 16-byte pieces per row
 #pragma unroll
     for (int i = 0; i < NPT; i++) {
         const int q = tid + i * BC_THREADS;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (q < npieces) {
-            const int r = q >> 3, p = q & 7;
+            const int r = q / PPR, p = q % PPR;
             const char* ptr = rowptr[r];
             const int kel = k0 + p * E::VEC;
             if (ptr != nullptr && kel < d) v = *reinterpret_cast<const uint4*>(ptr + (size_t)kel * sizeof(S));
@@ -379,38 +395,48 @@ __device__ __forceinline__ void slab_load(uint4* pre, const char* const* rowptr,
         pre[i] = v;
     }
 }
-template <int NPT>
+template <int NPT, int SW>
 __device__ __forceinline__ void slab_store(const uint4* pre, char* slab, int npieces, int tid) {
+    constexpr int PPR = 8 * SW, RSB = SW * 128 + 16;
 #pragma unroll
     for (int i = 0; i < NPT; i++) {
         const int q = tid + i * BC_THREADS;
-        if (q < npieces) *reinterpret_cast<uint4*>(slab + (q >> 3) * RS + (q & 7) * 16) = pre[i];
+        if (q < npieces) *reinterpret_cast<uint4*>(slab + (q / PPR) * RSB + (q % PPR) * 16) = pre[i];
     }
 }
 
-// NPT = 16-byte pieces a thread stages per k-slab: ceil((kx+ky)*48*8 / 512)
-template <typename E, int NPT>
+// NPT = 16-byte pieces a thread stages per k-slab: ceil((kx+ky)*48*8*SW / 512)
+template <typename E, int NPT, int SW>
 __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky, int chunk_a, int chunk_b, char* smem) {
     using S = typename E::storage;
     using M = Mma<E>;
+    constexpr int RSB = SW * 128 + 16;
+    constexpr int KSB = M::KS * SW, NKB = M::NK * SW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = 2 * g.W;
     const int a0 = chunk_a * TA;
     const int TAe = (g.A - a0) < TA ? (g.A - a0) : TA;
     const int b0 = chunk_b * TB;
     const int TBe = (B - b0) < TB ? (B - b0) : TB;
+    const int NR = (kx + ky) * ROWS;
+    const int npieces = NR * 8 * SW;
+    const BandLds L = band_lds(kx, ky, SW, ty.n < TPP ? ty.n : TPP);
     int* spx = reinterpret_cast<int*>(smem);
     int* spy = spx + TA;
-    const char** rowptr = reinterpret_cast<const char**>(smem + 2 * TA * sizeof(int));
-    const int NR = (kx + ky) * ROWS;
-    const int npieces = NR * 8;
-    size_t hdr = 2 * TA * sizeof(int) + (size_t)NR * sizeof(char*);
-    hdr = (hdr + 15) & ~(size_t)15;
-    char* slab = smem + hdr;
+    int* ltx = spy + TA;                      // alignment type sizes (kernel-argument arrays cannot be indexed
+    int* lty = ltx + (SVX_MAX_TYPES + 2);     //  dynamically without a trip through scratch)
+    const char** rowptr = reinterpret_cast<const char**>(smem + L.off_rowptr);
+    float* snrm = reinterpret_cast<float*>(smem + L.off_scal);  // [NR] normaliser of each staged row
+    float* sinv = snrm + NR;                                     // [NR] inverse norm (1 when rows are unit)
+    char* slab = smem + L.off_work;
 
     if (tid < TAe) {
         spx[tid] = g.path[2 * (a0 + tid)];
         spy[tid] = g.path[2 * (a0 + tid) + 1];
+    }
+    for (int t = tid; t < ty.n; t += BC_THREADS) {
+        ltx[t] = ty.x[t];
+        lty[t] = ty.y[t];
     }
     __syncthreads();
     if (tid < TAe) {
@@ -431,11 +457,30 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
         const int layer = rr / ROWS, loc = rr % ROWS;
         const int gi = (side ? Y0 : X0) + loc;
         const int nn = side ? g.m : g.n;
+        const bool live = loc < (side ? NYn : NXn) && gi >= 0 && gi < nn;
         const char* base = reinterpret_cast<const char*>(side ? g.v1 : g.v0);
-        rowptr[r] = (loc < (side ? NYn : NXn) && gi >= 0 && gi < nn) ? base + ((size_t)layer * nn + gi) * g.d * sizeof(S) : nullptr;
+        rowptr[r] = live ? base + ((size_t)layer * nn + gi) * g.d * sizeof(S) : nullptr;
+        const float* nr = side ? g.nrm1 : g.nrm0;
+        const float* iv = side ? g.inv1 : g.inv0;
+        snrm[r] = live ? nr[(size_t)layer * nn + gi] : 0.f;
+        sinv[r] = (live && iv) ? iv[(size_t)layer * nn + gi] : 1.f;
     }
     __syncthreads();
-    const int loff = M::lane_off(lane);
+    const int loff = (lane & 15) * RSB + (int)(sizeof(S) == 4 ? 4 : 16) * (lane >> 4);
+
+    // this thread's output cell (one per thread: TAe * TBe <= 512)
+    const int ncells = TAe * TBe;
+    const int c_ai = tid / TBe, c_bi = tid - c_ai * TBe;
+    int c_xloc = 0, c_yloc = 0;
+    bool c_in = false;
+    if (tid < ncells) {
+        const int yy = spy[c_ai] - g.W + b0 + c_bi;
+        const int xx = (a0 + c_ai) - yy;
+        c_xloc = xx - X0;  // 0 <= xloc, yloc <= 46 for a unit-step path
+        c_yloc = yy - Y0;
+        c_in = xx >= 0 && xx < g.n && yy >= 0 && yy < g.m;
+        if (c_xloc < 0 || c_xloc >= ROWS || c_yloc < 0 || c_yloc >= ROWS) { c_xloc = 0; c_yloc = 0; c_in = false; }
+    }
 
     for (int pass = 0; pass * TPP < ty.n; pass++) {
         const int ntp = (ty.n - pass * TPP) < TPP ? (ty.n - pass * TPP) : TPP;
@@ -449,102 +494,93 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
             const int u = wave + BC_WAVES * s;
             const int t = pass * TPP + (u < nunits ? u / 3 : 0);
             const int xt = u % 3;
-            aoff[s] = ((ty.x[t] - 1) * ROWS + xt * 16) * RS + loff;
-            boffs[s] = ((kx + ty.y[t] - 1) * ROWS) * RS + loff;
+            aoff[s] = ((ltx[t] - 1) * ROWS + xt * 16) * RSB + loff;
+            boffs[s] = ((kx + lty[t] - 1) * ROWS) * RSB + loff;
         }
-        // k loop, software-pipelined two slabs deep through two register sets: while the MFMAs run on
-        // slab k (in LDS), slab k+1 is already in flight in one set and slab k+2 is being issued into
-        // the other, so every global load has two iterations to land (one block per CU: this is what
-        // keeps enough bytes in flight).
-        uint4 preA[NPT], preB[NPT];
-        const int KS = M::KS;
-        auto mma_slab = [&]() {
+        // k loop: the global loads of slab k+1 are issued before the MFMAs of slab k
+        uint4 pre[NPT];
+        slab_load<E, NPT, SW>(pre, rowptr, npieces, 0, g.d, tid);
+        __syncthreads();  // the previous pass is done with the work area
+        slab_store<NPT, SW>(pre, slab, npieces, tid);
+        __syncthreads();
+        for (int k0 = 0; k0 < g.d; k0 += KSB) {
+            const bool more = k0 + KSB < g.d;
+            if (more) slab_load<E, NPT, SW>(pre, rowptr, npieces, k0 + KSB, g.d, tid);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < UPW; s++) {
                 if (wave + BC_WAVES * s < nunits) {  // wave-uniform
                     const char* ap = slab + aoff[s];
                     const char* bp = slab + boffs[s];
 #pragma unroll
-                    for (int ks = 0; ks < M::NK; ks++) {
+                    for (int ks = 0; ks < NKB; ks++) {
                         const typename M::frag fa = M::load(ap + ks * M::KSTEP_BYTES);
 #pragma unroll
                         for (int j = 0; j < 3; j++)
-                            M::mma(acc[s][j], fa, M::load(bp + j * 16 * RS + ks * M::KSTEP_BYTES));
+                            M::mma(acc[s][j], fa, M::load(bp + j * 16 * RSB + ks * M::KSTEP_BYTES));
                     }
                 }
             }
-        };
-        slab_load<E, NPT>(preA, rowptr, npieces, 0, g.d, tid);
-        __syncthreads();  // the previous pass is done with the dump (= slab)
-        slab_store<NPT>(preA, slab, npieces, tid);
-        if (KS < g.d) slab_load<E, NPT>(preA, rowptr, npieces, KS, g.d, tid);
-        __syncthreads();
-        for (int k0 = 0; k0 < g.d; k0 += 2 * KS) {
-            // LDS: slab k0; preA: slab k0+KS (in flight)
-            if (k0 + 2 * KS < g.d) slab_load<E, NPT>(preB, rowptr, npieces, k0 + 2 * KS, g.d, tid);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_slab();
             __syncthreads();  // every wave has read this slab
-            if (k0 + KS < g.d) {
-                slab_store<NPT>(preA, slab, npieces, tid);
-                __syncthreads();
-                // LDS: slab k0+KS; preB: slab k0+2KS (in flight)
-                if (k0 + 3 * KS < g.d) slab_load<E, NPT>(preA, rowptr, npieces, k0 + 3 * KS, g.d, tid);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_slab();
-                __syncthreads();
-                if (k0 + 2 * KS < g.d) slab_store<NPT>(preB, slab, npieces, tid);
-                __syncthreads();
-            }
+            if (more) slab_store<NPT, SW>(pre, slab, npieces, tid);
+            __syncthreads();
         }
-        // epilogue, one round per unit slot: every wave dumps the 16 x 48 accumulator block of its
-        // slot-s unit into LDS (aliasing the slab), then all threads walk the chunk's band cells in output
-        // order, pick their dot product out of the dump, apply the cost formula and store coalesced.
-        float* dump = reinterpret_cast<float*>(slab);  // [wave][16][48]
-        const int ncell = TAe * ntp * TBe;
+        // epilogue.  Work area = Fs [ai][type][bi] followed by the accumulator dump [unit][16][48].
+        // Rounds of SR unit slots: dump -> every thread looks its cell up in each dumped unit whose x tile
+        // contains the cell's row -> cost formula -> Fs.  Finally Fs is written out coalesced.
+        float* Fs = reinterpret_cast<float*>(slab);
+        float* dump = Fs + (size_t)ntp * TA * TB;
+        const int du = (int)((L.work_bytes - (size_t)ntp * TA * TB * sizeof(float)) / (DUMP_UNIT * sizeof(float)));
+        const int SR = du / BC_WAVES >= UPW ? UPW : (du / BC_WAVES < 1 ? 1 : du / BC_WAVES);
+        const int nslots = (nunits + BC_WAVES - 1) / BC_WAVES;
+        for (int s0 = 0; s0 < nslots; s0 += SR) {
 #pragma unroll
-        for (int s = 0; s < UPW; s++) {
-            if (BC_WAVES * s >= nunits) break;  // block-uniform
-            if (wave + BC_WAVES * s < nunits) {
-                float* dw = dump + wave * (16 * ROWS);
+            for (int s = 0; s < UPW; s++) {
+                if (s >= s0 && s < s0 + SR && wave + BC_WAVES * s < nunits) {
+                    float* dw = dump + ((s - s0) * BC_WAVES + wave) * DUMP_UNIT;
 #pragma unroll
-                for (int yt = 0; yt < 3; yt++)
+                    for (int yt = 0; yt < 3; yt++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) dw[((lane >> 4) * 4 + r) * ROWS + yt * 16 + (lane & 15)] = acc[s][yt][r];
-            }
-            __syncthreads();
-            for (int idx = tid; idx < ncell; idx += BC_THREADS) {
-                // idx -> (a, type, b): a-major like the [A][T][B] layout
-                const int ai = idx / (ntp * TBe);
-                const int rem = idx - ai * (ntp * TBe);
-                const int tl = rem / TBe, bi = rem - tl * TBe;
-                const int yy = spy[ai] - g.W + b0 + bi;
-                const int xx = (a0 + ai) - yy;
-                const int xloc = xx - X0, yloc = yy - Y0;  // 0 <= xloc, yloc < 47 for a unit-step path
-                const int u = tl * 3 + (xloc >> 4);
-                if ((u >> 3) != s || xloc < 0 || xloc >= ROWS || yloc < 0 || yloc >= ROWS) continue;
-                const int t = pass * TPP + tl;
-                const int p = ty.x[t], q = ty.y[t];
-                float c;
-                if (xx >= 0 && xx < g.n && yy >= 0 && yy < g.m) {
-                    float sumx = dump[(u & 7) * (16 * ROWS) + (xloc & 15) * ROWS + yloc];
-                    if (g.inv0) sumx = sumx * g.inv0[(size_t)(p - 1) * g.n + xx] * g.inv1[(size_t)(q - 1) * g.m + yy];
-                    c = cost_formula(sumx, p, q, g.nrm0[(size_t)(p - 1) * g.n + xx], g.nrm1[(size_t)(q - 1) * g.m + yy]);
-                } else {
-                    c = __builtin_inff();
+                        for (int r = 0; r < 4; r++) dw[((lane >> 4) * 4 + r) * ROWS + yt * 16 + (lane & 15)] = acc[s][yt][r];
                 }
-                const size_t o = g.atb ? ((size_t)(a0 + ai) * ty.n + t) * B + (b0 + bi) : ((size_t)t * g.A + (a0 + ai)) * B + (b0 + bi);
-                g.costs[o] = c;
             }
             __syncthreads();
+            if (tid < ncells) {
+                const int xq = c_xloc >> 4;
+                const int ulo = s0 * BC_WAVES, uhi = (s0 + SR) * BC_WAVES < nunits ? (s0 + SR) * BC_WAVES : nunits;
+                // units of this round whose x tile holds my row: u = 3*tl + xq
+                for (int tl = (ulo - xq + 2) / 3; 3 * tl + xq < uhi; tl++) {
+                    const int u = 3 * tl + xq;
+                    const int t = pass * TPP + tl;
+                    const int p = ltx[t], q = lty[t];
+                    float c = __builtin_inff();
+                    if (c_in) {
+                        const int rx = (p - 1) * ROWS + c_xloc, ry = (kx + q - 1) * ROWS + c_yloc;
+                        const float sumx = dump[(u - ulo) * DUMP_UNIT + (c_xloc & 15) * ROWS + c_yloc] * sinv[rx] * sinv[ry];
+                        c = cost_formula(sumx, p, q, snrm[rx], snrm[ry]);
+                    }
+                    Fs[((size_t)c_ai * ntp + tl) * TB + c_bi] = c;
+                }
+            }
+            __syncthreads();
+        }
+        // coalesced write-out of the [ai][type][bi] block
+        const int nout = TAe * ntp * TBe;
+        for (int idx = tid; idx < nout; idx += BC_THREADS) {
+            const int ai = idx / (ntp * TBe);
+            const int rem = idx - ai * (ntp * TBe);
+            const int tl = rem / TBe, bi = rem - tl * TBe;
+            const int t = pass * TPP + tl;
+            const size_t o = g.atb ? ((size_t)(a0 + ai) * ty.n + t) * B + (b0 + bi) : ((size_t)t * g.A + (a0 + ai)) * B + (b0 + bi);
+            g.costs[o] = Fs[((size_t)ai * ntp + tl) * TB + bi];
         }
     }
 }
 
-template <typename E, int NPT>
+template <typename E, int NPT, int SW>
 __global__ __launch_bounds__(BC_THREADS) void k_band_costs(BandArgs g, SvxTypes ty, int kx, int ky, int nchunk_b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    band_block<E, NPT>(g, ty, kx, ky, blockIdx.x / nchunk_b, blockIdx.x % nchunk_b, smem);
+    band_block<E, NPT, SW>(g, ty, kx, ky, blockIdx.x / nchunk_b, blockIdx.x % nchunk_b, smem);
 }
 
 // depth 0 uses the final types on the raw rows; deeper levels use (1,1) on normalised fp32 layer 0
@@ -557,7 +593,7 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned n) {
 }
 
 // depth 0 uses the final types on the raw rows; deeper levels use (1,1) on normalised fp32 layer 0
-template <typename E, bool LV0, int NPT>
+template <typename E, bool LV0, int NPT, int SW>
 __global__ __launch_bounds__(BC_THREADS) void k_band_costs_batch(const SvxPairDev* __restrict__ pairs, int depth, SvxTypes ty,
                                                                  int kx, int ky, int W, int nchunk_b, int per_pair) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -585,7 +621,7 @@ __global__ __launch_bounds__(BC_THREADS) void k_band_costs_batch(const SvxPairDe
     g.boff = Lv.boff;
     g.status = P.status;
     g.atb = 1;
-    band_block<E, NPT>(g, ty, kx, ky, chunk_a, item % nchunk_b, smem);
+    band_block<E, NPT, SW>(g, ty, kx, ky, chunk_a, item % nchunk_b, smem);
 }
 
 inline int nch_f32(int d) {
@@ -703,6 +739,45 @@ static int types_layers(const SvxTypes& ty, int* kx, int* ky) {
     return 0;
 }
 
+struct BandPlan {
+    int sw, npt;
+    size_t smem;
+};
+
+// Slab width and staging depth for a layer count: 256-byte slabs (half the barrier rounds) when the LDS
+// budget allows, else 128-byte slabs.
+static int band_plan(svx_ctx* ctx, int kx, int ky, int ntypes, BandPlan* bp) {
+    const int NR = (kx + ky) * ROWS;
+    const int ntp = ntypes < TPP ? ntypes : TPP;
+    for (int sw = 2; sw >= 1; sw--) {
+        const BandLds L = band_lds(kx, ky, sw, ntp);
+        const int npt = (NR * 8 * sw + BC_THREADS - 1) / BC_THREADS;
+        if (sw == 2 && (L.total > 128 * 1024 || npt > 12)) continue;
+        if (L.total > 160 * 1024 || npt > 14)
+            return svx_fail(ctx, SVX_ERR_ARG, "band costs: %d+%d overlap layers need %zu bytes of LDS / %d staging pieces (limits 160 KiB / 14)",
+                            kx, ky, L.total, npt);
+        bp->sw = sw;
+        bp->npt = npt < 1 ? 1 : npt;
+        bp->smem = L.total;
+        return SVX_OK;
+    }
+    return svx_fail(ctx, SVX_ERR_ARG, "band costs: no launch configuration");
+}
+
+#define BAND_DISPATCH(CALL)                      \
+    do {                                         \
+        if (bp.sw == 2) {                        \
+            if (bp.npt <= 3) CALL(3, 2);         \
+            else if (bp.npt <= 6) CALL(6, 2);    \
+            else CALL(12, 2);                    \
+        } else {                                 \
+            if (bp.npt <= 2) CALL(2, 1);         \
+            else if (bp.npt <= 6) CALL(6, 1);    \
+            else if (bp.npt <= 8) CALL(8, 1);    \
+            else CALL(14, 1);                    \
+        }                                        \
+    } while (0)
+
 int svxl_band_costs(svx_ctx* ctx, const void* v0, int k0, int n, const void* v1, int k1, int m, int d, int dtype,
                     const float* inv0, const float* inv1, const float* nrm0, const float* nrm1, const int* path, int A,
                     const SvxTypes& types, int W, float* costs, int* boff, int* status) {
@@ -710,37 +785,31 @@ int svxl_band_costs(svx_ctx* ctx, const void* v0, int k0, int n, const void* v1,
     int kx, ky;
     types_layers(types, &kx, &ky);
     if (kx > k0 || ky > k1) return svx_fail(ctx, SVX_ERR_OVERLAPS, "overlaps");
-    if (types.n == 0) {
-        // only b_offset is produced (costs has shape [0][A][B]); stage zero layers, zero passes
-        kx = 0;
-        ky = 0;
-    }
-    const size_t smem = band_smem_bytes(kx, ky);
-    if (smem > 160 * 1024) return svx_fail(ctx, SVX_ERR_ARG, "band costs: %d+%d overlap layers need %zu bytes of LDS (>160 KiB)", kx, ky, smem);
+    if (types.n == 0) kx = ky = 0;  // only b_offset is produced (costs has shape [0][A][B])
+    BandPlan bp;
+    int rc = band_plan(ctx, kx, ky, types.n, &bp);
+    if (rc) return rc;
+    const size_t smem = bp.smem;
     const int B = 2 * W;
     const int nca = (A + TA - 1) / TA, ncb = (B + TB - 1) / TB;
     BandArgs g{v0, v1, n, m, d, inv0, inv1, nrm0, nrm1, path, A, W, costs, boff, status, 0};
     dim3 grid((unsigned)(nca * ncb));
-    const int npt = ((kx + ky) * ROWS * 8 + BC_THREADS - 1) / BC_THREADS;
-#define LAUNCH2(E, NPT)                                                                                             \
+#define CALL_E(E, NPT, SW)                                                                                          \
     do {                                                                                                            \
         if (smem > 64 * 1024)                                                                                       \
-            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_band_costs<E, NPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL((k_band_costs<E, NPT>), grid, dim3(BC_THREADS), smem, ctx->stream, g, types, kx, ky, ncb); \
+            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_band_costs<E, NPT, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_band_costs<E, NPT, SW>), grid, dim3(BC_THREADS), smem, ctx->stream, g, types, kx, ky, ncb); \
     } while (0)
-#define LAUNCH(E)                                                                                                   \
-    do {                                                                                                            \
-        if (npt <= 2) LAUNCH2(E, 2);                                                                                \
-        else if (npt <= 6) LAUNCH2(E, 6);                                                                           \
-        else if (npt <= 8) LAUNCH2(E, 8);                                                                           \
-        else LAUNCH2(E, 14);                                                                                        \
-    } while (0)
-    if (npt > 14) return svx_fail(ctx, SVX_ERR_ARG, "band costs: %d+%d overlap layers exceed the staging limit (18)", kx, ky);
-    if (dtype == SVX_F32) LAUNCH(ElemF32);
-    else if (dtype == SVX_F16) LAUNCH(ElemF16);
-    else LAUNCH(ElemBF16);
-#undef LAUNCH
-#undef LAUNCH2
+#define CALL_F32(NPT, SW) CALL_E(ElemF32, NPT, SW)
+#define CALL_F16(NPT, SW) CALL_E(ElemF16, NPT, SW)
+#define CALL_BF16(NPT, SW) CALL_E(ElemBF16, NPT, SW)
+    if (dtype == SVX_F32) BAND_DISPATCH(CALL_F32);
+    else if (dtype == SVX_F16) BAND_DISPATCH(CALL_F16);
+    else BAND_DISPATCH(CALL_BF16);
+#undef CALL_F32
+#undef CALL_F16
+#undef CALL_BF16
+#undef CALL_E
     SVX_LAUNCH_CHECK(ctx, "k_band_costs");
     return SVX_OK;
 }
@@ -752,33 +821,33 @@ int svxl_band_costs_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, in
     int kx, ky;
     types_layers(types, &kx, &ky);
     if (types.n == 0) kx = ky = 0;
-    const size_t smem = band_smem_bytes(kx, ky);
-    if (smem > 160 * 1024) return svx_fail(ctx, SVX_ERR_ARG, "band costs: %d+%d overlap layers need %zu bytes of LDS (>160 KiB)", kx, ky, smem);
+    BandPlan bp;
+    int rc = band_plan(ctx, kx, ky, types.n, &bp);
+    if (rc) return rc;
+    const size_t smem = bp.smem;
     const int B = 2 * W;
     const int nca = (max_A + TA - 1) / TA, ncb = (B + TB - 1) / TB;
     const int per_pair = nca * ncb;
     dim3 grid((unsigned)per_pair * (unsigned)n_pairs);
-    const int npt = ((kx + ky) * ROWS * 8 + BC_THREADS - 1) / BC_THREADS;
-#define LAUNCH2(E, LV0, NPT)                                                                                        \
+#define CALL_E(E, LV0, NPT, SW)                                                                                     \
     do {                                                                                                            \
         if (smem > 64 * 1024)                                                                                       \
-            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_band_costs_batch<E, LV0, NPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL((k_band_costs_batch<E, LV0, NPT>), grid, dim3(BC_THREADS), smem, ctx->stream, pairs, depth, types, kx, ky, W, ncb, per_pair); \
+            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_band_costs_batch<E, LV0, NPT, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_band_costs_batch<E, LV0, NPT, SW>), grid, dim3(BC_THREADS), smem, ctx->stream, pairs, depth, types, kx, ky, W, ncb, per_pair); \
     } while (0)
-#define LAUNCH(E, LV0)                                                                                              \
-    do {                                                                                                            \
-        if (npt <= 2) LAUNCH2(E, LV0, 2);                                                                           \
-        else if (npt <= 6) LAUNCH2(E, LV0, 6);                                                                      \
-        else if (npt <= 8) LAUNCH2(E, LV0, 8);                                                                      \
-        else LAUNCH2(E, LV0, 14);                                                                                   \
-    } while (0)
-    if (npt > 14) return svx_fail(ctx, SVX_ERR_ARG, "band costs: %d+%d overlap layers exceed the staging limit (18)", kx, ky);
-    if (depth > 0) LAUNCH(ElemF32, false);
-    else if (dtype == SVX_F32) LAUNCH(ElemF32, true);
-    else if (dtype == SVX_F16) LAUNCH(ElemF16, true);
-    else LAUNCH(ElemBF16, true);
-#undef LAUNCH
-#undef LAUNCH2
+#define CALL_DEEP(NPT, SW) CALL_E(ElemF32, false, NPT, SW)
+#define CALL_F32(NPT, SW) CALL_E(ElemF32, true, NPT, SW)
+#define CALL_F16(NPT, SW) CALL_E(ElemF16, true, NPT, SW)
+#define CALL_BF16(NPT, SW) CALL_E(ElemBF16, true, NPT, SW)
+    if (depth > 0) BAND_DISPATCH(CALL_DEEP);
+    else if (dtype == SVX_F32) BAND_DISPATCH(CALL_F32);
+    else if (dtype == SVX_F16) BAND_DISPATCH(CALL_F16);
+    else BAND_DISPATCH(CALL_BF16);
+#undef CALL_DEEP
+#undef CALL_F32
+#undef CALL_F16
+#undef CALL_BF16
+#undef CALL_E
     SVX_LAUNCH_CHECK(ctx, "k_band_costs_batch");
     return SVX_OK;
 }
