@@ -65,9 +65,9 @@ def dp_cells(N, M, W, max_full, types):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=64, help="document pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=512, help="document pairs per GPU per step")
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--d", type=int, default=1024)
@@ -114,8 +114,9 @@ def main():
     first = pb.results() if args.warmup > 0 else None
     if not args.no_profile:
         lib.svx_set_profiling(ctx.h, 1)
-    stage_names = ["pyr0", "pyrN", "knob_scores", "knob", "dense_costs", "dense_dp", "path", "band_costs0", "band_costsN",
-                   "band_dp0", "band_dpN", "traceback", "setup", "total", "host_plan", "host_launch"]
+    stage_names = ["pyr0", "pyrN", "pyr_aux", "knob_sort", "knob_scores0", "knob_scoresN", "knob", "dense_costs", "dense_dp",
+                   "path", "band_costs0", "band_costsN", "band_dp0", "band_dpN", "traceback", "setup", "total", "host_plan",
+                   "host_launch"]
     stage_ms = {s: 0.0 for s in stage_names}
     stage_launch = {s: 0 for s in stage_names}
 
@@ -156,23 +157,43 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (HIP events on the launch stream, timed region)
-        alg_bytes_pair = K * (N + M) * d * esz  # every candidate embedding read once
+        # ---- roofline of the dominant kernel (HIP events on the launch stream, timed region).
+        # Algorithmic bytes = what the kernel must move once given its inputs and outputs;
+        # the whole-path figure of SURVEY.md 8(d) is K(N+M)d*e = every candidate embedding read once.
+        sizes = [(N, M)]
+        while sizes[-1][0] * sizes[-1][1] > 300 * 300:
+            sizes.append((sizes[-1][0] // 2, sizes[-1][1] // 2))
+        L = len(sizes) - 1
+        T = len(types)
+        Bw = 2 * W
+        row0 = d * esz
+        alg = {
+            "pyr0": K * (N + M) * row0 + (K * (sizes[1][0] + sizes[1][1]) * d * 4 if L >= 1 else 0),
+            "pyrN": sum(K * (a + b) * d * 4 + (a + b) * d * 4 + (K * (sizes[l + 1][0] + sizes[l + 1][1]) * d * 4 if l < L else 0)
+                        for l, (a, b) in enumerate(sizes) if l >= 1),
+            "knob_scores0": (20000 + N) * row0,
+            "knob_scoresN": sum((20000 + a) * d * 4 for l, (a, b) in enumerate(sizes) if l >= 1),
+            "band_costs0": K * (N + M) * row0 + T * (N + M + 3) * Bw * 4,
+            "band_costsN": sum((a + b) * d * 4 + (a + b + 3) * Bw * 4 for l, (a, b) in enumerate(sizes) if 1 <= l < L),
+            "band_dp0": (T * 4 + 9) * (N + M + 5) * Bw,
+            "band_dpN": sum(13 * (a + b + 5) * Bw for l, (a, b) in enumerate(sizes) if 1 <= l < L),
+        }
+        alg_bytes_pair = K * (N + M) * row0
         if not args.no_profile and stage_ms["total"] > 0:
-            kernels = {k: v for k, v in stage_ms.items() if k not in ("total", "setup", "host_plan", "host_launch")}
+            kernels = {k: v for k, v in stage_ms.items() if k in alg}
             dom = max(kernels, key=kernels.get)
             launches = max(1, stage_launch[dom])
             avg_ms = kernels[dom] / launches
-            # pairs a launch processes: every launch of a stage covers the whole batch
-            per_launch_bytes = alg_bytes_pair * P
-            if dom in ("pyrN", "band_costsN", "band_dpN", "path", "traceback"):
-                per_launch_bytes = alg_bytes_pair * P  # multi-launch stages: bytes of the level-0 stream as the yardstick
+            per_launch_bytes = alg[dom] * P * args.steps / launches
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                                "frac": achieved / 8000.0, "traffic": None,
                                "avg_launch_ms": avg_ms, "launches": launches,
-                               "algorithmic_bytes_per_launch": per_launch_bytes}
+                               "algorithmic_bytes_per_launch": per_launch_bytes,
+                               "whole_path_input_bytes_per_pair": alg_bytes_pair,
+                               "whole_path_GBps": alg_bytes_pair * value / max(1, world) / 1e9}
             out["stage_ms_per_step"] = {k: v / args.steps for k, v in stage_ms.items()}
+            out["kernel_GBps"] = {k: alg[k] * P * args.steps / (stage_ms[k] * 1e-3) / 1e9 for k in alg if stage_ms[k] > 0}
         # ---- CPU baseline: the oracle (restatement of the reference, pinned bit-exact against it) on one thread
         if world == 1 and args.cpu_pairs > 0:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -167,8 +167,10 @@ int64_t svx_knob_count(int n_l, int m_l, int costs_sample_size);
 int svx_align_batch(svx_ctx *ctx, const svx_align_params *params, const svx_pair *pairs, int n_pairs);
 
 /* Device time of the named stage of the last svx_align_batch call, in milliseconds, measured with
- * HIP events on the context's stream when profiling is on (svx_set_profiling); stage names:
- * "pyramid", "knob", "dense", "path", "band_costs", "band_dp", "traceback", "total"; "host_plan"/"host_launch" are host wall-clock. -1 if unknown. */
+ * HIP events on the context's stream when profiling is on (svx_set_profiling); one name per kernel:
+ * "pyr0" "pyrN" "pyr_aux" "knob_sort" "knob_scores0" "knob_scoresN" "knob" "dense_costs" "dense_dp" "path"
+ * "band_costs0" "band_costsN" "band_dp0" "band_dpN" "traceback" "setup" "total" (0 = level 0, N = deeper levels);
+ * "host_plan"/"host_launch" are host wall-clock.  -1 if unknown. */
 int svx_set_profiling(svx_ctx *ctx, int on);
 /* Number of internal streams svx_align_batch splits a batch over (1..4, default 1): the serial
  * kernels of one sub-batch overlap the streaming kernels of the others.  Results do not depend on it. */

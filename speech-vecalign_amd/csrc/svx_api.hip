@@ -21,12 +21,12 @@ int svx_fail(svx_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
-static const char* kStageNames[] = {"pyr0",       "pyrN",     "pyr_aux",      "knob_scores",  "knob",      "dense_costs",
+static const char* kStageNames[] = {"pyr0",       "pyrN",     "pyr_aux",      "knob_scoresN", "knob",      "dense_costs",
                                     "dense_dp",   "path",     "band_costs0",  "band_costsN",  "band_dp0",  "band_dpN",
-                                    "traceback",  "setup",    "total",        "host_plan",    "host_launch"};
+                                    "traceback",  "setup",    "total",        "host_plan",    "host_launch", "knob_sort", "knob_scores0"};
 enum {
     S_PYR0 = 0, S_PYRN, S_PYR_AUX, S_KNOB_SCORES, S_KNOB, S_DENSE_COSTS, S_DENSE_DP, S_PATH, S_BAND_COSTS0, S_BAND_COSTSN,
-    S_BAND_DP0, S_BAND_DPN, S_TRACEBACK, S_SETUP, S_TOTAL, S_HOST_PLAN, S_HOST_LAUNCH, S_COUNT
+    S_BAND_DP0, S_BAND_DPN, S_TRACEBACK, S_SETUP, S_TOTAL, S_HOST_PLAN, S_HOST_LAUNCH, S_KNOB_SORT, S_KNOB_SCORES0, S_COUNT
 };
 
 struct StageRec {
@@ -551,12 +551,24 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         int rc2;
         for (int l = 0; l <= maxL; l++) {
             // pyramid: the streaming pass of level l (S_PYR0 / S_PYRN) and its small helpers
+            {
+                StageScope sc(ctx, S_PYR_AUX);
+                if ((rc2 = svxl_pyramid_level(ctx, dp, np, l, dtype, d, max_nblk[l], max_ksum, 0))) return rc2;
+            }
             StageScope sc(ctx, l == 0 ? S_PYR0 : S_PYRN);
-            if ((rc2 = svxl_pyramid_level(ctx, dp, np, l, dtype, d, max_nblk[l], max_ksum, 0))) return rc2;
+            if ((rc2 = svxl_pyramid_level(ctx, dp, np, l, dtype, d, max_nblk[l], max_ksum, 1))) return rc2;
         }
         {
+            StageScope sc(ctx, S_KNOB_SORT);
+            if ((rc2 = svxl_knob_scores(ctx, dp, np, maxL, max_kn, max_n0, dtype, d, 0))) return rc2;
+        }
+        if (maxL >= 1) {
             StageScope sc(ctx, S_KNOB_SCORES);
-            if ((rc2 = svxl_knob_scores(ctx, dp, np, maxL, max_kn, max_n0, dtype, d))) return rc2;
+            if ((rc2 = svxl_knob_scores(ctx, dp, np, maxL, max_kn, max_n0, dtype, d, 1))) return rc2;
+        }
+        {
+            StageScope sc(ctx, S_KNOB_SCORES0);
+            if ((rc2 = svxl_knob_scores(ctx, dp, np, maxL, max_kn, max_n0, dtype, d, 2))) return rc2;
         }
         {
             StageScope sc(ctx, S_KNOB);

@@ -160,11 +160,12 @@ int svxl_sub_mean(svx_ctx*, float* half, int k, int h, int d, const float* mean)
 int svxl_sample_mean_plain(svx_ctx*, const float* vecs, int k, int n, int d, const int* idx, int S, float* rbar);
 int svxl_norms_from_rbar(svx_ctx*, const float* vecs, int64_t rows, int d, const float* rbar, float* norms);
 int svxl_pyramid_level(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int level, int dtype, int d, int max_nblk,
-                       int max_ksum, int max_npart);
+                       int max_ksum, int part);
 // costs (svx_costs.hip)
 int svxl_score_path(svx_ctx*, const int* xx, const int* yy, int64_t n, const float* n1, const float* n2,
                     const float* v1, int rows1, const float* v2, int rows2, int d, float* out);
-int svxl_knob_scores(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_levels, int max_kn, int max_n0, int dtype, int d);
+int svxl_knob_scores(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_levels, int max_kn, int max_n0, int dtype, int d,
+                     int part);
 int svxl_dense_costs(svx_ctx*, const float* v0, int s0, const float* v1, int s1, int d, const float* n0,
                      const float* n1, int mul0, int mul1, float* costs);
 int svxl_dense_costs_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_s0, int max_s1, int dtype, int d);

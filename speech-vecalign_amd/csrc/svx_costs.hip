@@ -222,6 +222,8 @@ __global__ __launch_bounds__(256) void k_score_path(ScoreArgs g) {
     score_block<E, NCH>(g, (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), (int64_t)gridDim.x * 4);
 }
 
+__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned n);  // defined with the band kernels below
+
 // Counting sort of one level's knob samples by source row (one workgroup per (level, pair)):
 // korder = sample ids grouped by x, kstart[x] = first position of row x.  max and histogram do not
 // care about sample order, so the scoring kernel may visit the samples row by row and read every
@@ -272,13 +274,17 @@ __global__ __launch_bounds__(256) void k_knob_sort(const SvxPairDev* __restrict_
 }
 
 // One wave per source row x: the row stays in registers while the wave walks the samples (x, y_s).
-// level = blockIdx.y + (LV0 ? 0 : 1)
+// The grid is 1-D over (pair, level) tasks x `bpt` workgroups; after the XCD remap a task's workgroups
+// share one XCD, so the randomly gathered target rows of that level are served by one L2 instead of
+// being spread over eight.  level = task % nlev + (LV0 ? 0 : 1).
 template <typename E, int NCH, bool LV0>
-__global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restrict__ pairs) {
+__global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restrict__ pairs, int nlev, int bpt) {
     using S = typename E::storage;
     constexpr int EPL = NCH * E::VEC;
-    const SvxPairDev& P = pairs[blockIdx.z];
-    const int level = LV0 ? 0 : (int)blockIdx.y + 1;
+    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int task = wg / bpt, blk = wg % bpt;
+    const SvxPairDev& P = pairs[task / nlev];
+    const int level = task % nlev + (LV0 ? 0 : 1);
     if (level > P.L) return;
     const SvxLevel& Lv = P.lev[level];
     const int lane = threadIdx.x & 63;
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restric
     const S* v2 = LV0 ? reinterpret_cast<const S*>(P.v[1]) : reinterpret_cast<const S*>(Lv.P[1]);
     const float* inv1 = LV0 ? Lv.inv[0] : nullptr;
     const float* inv2 = LV0 ? Lv.inv[1] : nullptr;
-    for (int x = blockIdx.x * 4 + (threadIdx.x >> 6); x < n; x += gridDim.x * 4) {
+    for (int x = blk * 4 + (threadIdx.x >> 6); x < n; x += bpt * 4) {
         const int s0 = Lv.kstart[x], s1 = Lv.kstart[x + 1];
         if (s0 >= s1) continue;  // wave-uniform
         float xr[EPL];
@@ -584,6 +590,7 @@ __global__ __launch_bounds__(BC_THREADS) void k_band_costs(BandArgs g, SvxTypes 
 }
 
 // depth 0 uses the final types on the raw rows; deeper levels use (1,1) on normalised fp32 layer 0
+// depth 0 uses the final types on the raw rows; deeper levels use (1,1) on normalised fp32 layer 0
 // Workgroups are dealt round-robin over the 8 XCDs (id % 8).  Remap the linear id so that each XCD
 // owns one contiguous range of (pair, chunk) work items: neighbouring chunks share up to 2W rows per
 // side, and with this map they share them through the same L2 (speed only, never correctness).
@@ -679,22 +686,25 @@ int svxl_score_path(svx_ctx* ctx, const int* xx, const int* yy, int64_t n, const
     return SVX_OK;
 }
 
-int svxl_knob_scores(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int max_L, int max_kn, int max_n0, int dtype, int d) {
+// part 0: counting sort by source row; part 1: levels >= 1 (fp32 rows); part 2: level 0 (input dtype)
+int svxl_knob_scores(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int max_L, int max_kn, int max_n0, int dtype, int d,
+                     int part) {
     if (n_pairs <= 0 || max_kn <= 0) return SVX_OK;
     hipStream_t st = ctx->stream;
-    {
+    if (part == 0) {
         const size_t smem = (size_t)(max_n0 + 1) * sizeof(int);
         if (smem > 150 * 1024) return svx_fail(ctx, SVX_ERR_ARG, "knob sort: %d source rows exceed the LDS histogram", max_n0);
         if (smem > 64 * 1024)
             SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_knob_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(k_knob_sort, dim3(max_L + 1, n_pairs), dim3(256), smem, st, pairs);
         SVX_LAUNCH_CHECK(ctx, "k_knob_sort");
+        return SVX_OK;
     }
     int nb = (max_n0 + 3) / 4;  // one wave per source row
-    if (nb > 2048) nb = 2048;
-#define M32(N, LV0, GY) hipLaunchKernelGGL((k_knob_scores<ElemF32, N, LV0>), dim3(nb, GY, n_pairs), dim3(256), 0, st, pairs)
-#define M16(E, N) hipLaunchKernelGGL((k_knob_scores<E, N, true>), dim3(nb, 1, n_pairs), dim3(256), 0, st, pairs)
-    if (max_L >= 1) {
+    if (nb > 1024) nb = 1024;
+#define M32(N, LV0, GY) hipLaunchKernelGGL((k_knob_scores<ElemF32, N, LV0>), dim3((unsigned)nb * (GY) * n_pairs), dim3(256), 0, st, pairs, GY, nb)
+#define M16(E, N) hipLaunchKernelGGL((k_knob_scores<E, N, true>), dim3((unsigned)nb * n_pairs), dim3(256), 0, st, pairs, 1, nb)
+    if (part == 1 && max_L >= 1) {
         switch (nch_f32(d)) {
             case 1: M32(1, false, max_L); break;
             case 2: M32(2, false, max_L); break;
@@ -702,7 +712,8 @@ int svxl_knob_scores(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int max
             default: M32(8, false, max_L); break;
         }
     }
-    if (dtype == SVX_F32) {
+    if (part != 2) {
+    } else if (dtype == SVX_F32) {
         switch (nch_f32(d)) {
             case 1: M32(1, true, 1); break;
             case 2: M32(2, true, 1); break;
@@ -744,14 +755,15 @@ struct BandPlan {
     size_t smem;
 };
 
-// Slab width and staging depth for a layer count: 256-byte slabs (half the barrier rounds) when the LDS
-// budget allows, else 128-byte slabs.
+// Slab width and staging depth for a layer count: the widest k-slab the LDS budget allows (512 bytes for
+// single-layer levels, else 256, else 128): wider slabs mean fewer barrier rounds per workgroup.
 static int band_plan(svx_ctx* ctx, int kx, int ky, int ntypes, BandPlan* bp) {
     const int NR = (kx + ky) * ROWS;
     const int ntp = ntypes < TPP ? ntypes : TPP;
-    for (int sw = 2; sw >= 1; sw--) {
+    for (int sw = 4; sw >= 1; sw >>= 1) {
         const BandLds L = band_lds(kx, ky, sw, ntp);
         const int npt = (NR * 8 * sw + BC_THREADS - 1) / BC_THREADS;
+        if (sw == 4 && (NR > 2 * ROWS || L.total > 64 * 1024)) continue;  // 512-byte slabs: single-layer levels only
         if (sw == 2 && (L.total > 128 * 1024 || npt > 12)) continue;
         if (L.total > 160 * 1024 || npt > 14)
             return svx_fail(ctx, SVX_ERR_ARG, "band costs: %d+%d overlap layers need %zu bytes of LDS / %d staging pieces (limits 160 KiB / 14)",
@@ -766,7 +778,9 @@ static int band_plan(svx_ctx* ctx, int kx, int ky, int ntypes, BandPlan* bp) {
 
 #define BAND_DISPATCH(CALL)                      \
     do {                                         \
-        if (bp.sw == 2) {                        \
+        if (bp.sw == 4) {                        \
+            CALL(6, 4);                          \
+        } else if (bp.sw == 2) {                 \
             if (bp.npt <= 3) CALL(3, 2);         \
             else if (bp.npt <= 6) CALL(6, 2);    \
             else CALL(12, 2);                    \

@@ -478,38 +478,38 @@ int svxl_norms_from_rbar(svx_ctx* ctx, const float* vecs, int64_t rows, int d, c
 
 // One pyramid level of the fused pipeline: (level >= 1: column means) -> sampled-row means ->
 // the streaming pass (norms, normalisers, normalised layer 0, pair sums for level+1).
+// part 0: the small helpers (column means of this level, sampled-row means); part 1: the streaming pass.
 int svxl_pyramid_level(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int level, int dtype, int d, int max_nblk,
-                       int max_ksum, int max_npart) {
-    (void)max_npart;
+                       int max_ksum, int part) {
     if (n_pairs <= 0 || max_nblk <= 0) return SVX_OK;
     hipStream_t st = ctx->stream;
-    if (level >= 1) {
+    if (part == 0 && level >= 1) {
         hipLaunchKernelGGL(k_colmean, dim3((d + 255) / 256, max_ksum, n_pairs), dim3(256), 0, st, pairs, level);
         SVX_LAUNCH_CHECK(ctx, "k_colmean");
-#define M(N)                                                                                                      \
-    hipLaunchKernelGGL((k_sample_mean<ElemF32, N, false>), dim3(2, n_pairs), dim3(256), 0, st, pairs, level);      \
-    hipLaunchKernelGGL((k_pyramid<ElemF32, N, false>), dim3(max_nblk, max_ksum, n_pairs), dim3(256), 0, st, pairs, level)
+    }
+#define LAUNCH(E, N, LV0)                                                                                              \
+    do {                                                                                                               \
+        if (part == 0) hipLaunchKernelGGL((k_sample_mean<E, N, LV0>), dim3(2, n_pairs), dim3(256), 0, st, pairs, level); \
+        else hipLaunchKernelGGL((k_pyramid<E, N, LV0>), dim3(max_nblk, max_ksum, n_pairs), dim3(256), 0, st, pairs, level); \
+    } while (0)
+    if (level >= 1) {
+#define M(N) LAUNCH(ElemF32, N, false)
         SVX_SWITCH_NCH_F32(d, M)
 #undef M
     } else if (dtype == SVX_F32) {
-#define M(N)                                                                                                     \
-    hipLaunchKernelGGL((k_sample_mean<ElemF32, N, true>), dim3(2, n_pairs), dim3(256), 0, st, pairs, level);      \
-    hipLaunchKernelGGL((k_pyramid<ElemF32, N, true>), dim3(max_nblk, max_ksum, n_pairs), dim3(256), 0, st, pairs, level)
+#define M(N) LAUNCH(ElemF32, N, true)
         SVX_SWITCH_NCH_F32(d, M)
 #undef M
     } else if (dtype == SVX_F16) {
-#define M(N)                                                                                                     \
-    hipLaunchKernelGGL((k_sample_mean<ElemF16, N, true>), dim3(2, n_pairs), dim3(256), 0, st, pairs, level);      \
-    hipLaunchKernelGGL((k_pyramid<ElemF16, N, true>), dim3(max_nblk, max_ksum, n_pairs), dim3(256), 0, st, pairs, level)
+#define M(N) LAUNCH(ElemF16, N, true)
         SVX_SWITCH_NCH_16(d, M)
 #undef M
     } else {
-#define M(N)                                                                                                      \
-    hipLaunchKernelGGL((k_sample_mean<ElemBF16, N, true>), dim3(2, n_pairs), dim3(256), 0, st, pairs, level);      \
-    hipLaunchKernelGGL((k_pyramid<ElemBF16, N, true>), dim3(max_nblk, max_ksum, n_pairs), dim3(256), 0, st, pairs, level)
+#define M(N) LAUNCH(ElemBF16, N, true)
         SVX_SWITCH_NCH_16(d, M)
 #undef M
     }
+#undef LAUNCH
     SVX_LAUNCH_CHECK(ctx, "k_pyramid");
     return SVX_OK;
 }
