@@ -186,8 +186,23 @@ def main():
             avg_ms = kernels[dom] / launches
             per_launch_bytes = alg[dom] * P * args.steps / launches
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+            # HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of
+            # MI355X_MICROARCH.md), measured separately per pair and scaled to this launch: profiles/r01_hbm_traffic.json
+            traffic = None
+            try:
+                import re
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))["hbm_bytes_per_pair_per_launch"]
+                pat = {"pyr0": r"k_pyramid<.*true>", "pyrN": r"k_pyramid<ElemF32, \d+, false>", "knob_scores0": r"k_knob_scores<.*true>",
+                       "knob_scoresN": r"k_knob_scores<ElemF32, \d+, false>", "band_costs0": r"k_band_costs_batch<.*true",
+                       "band_costsN": r"k_band_costs_batch<ElemF32, false", "band_dp0": r"k_sparse_dp_fast_batch<3>",
+                       "band_dpN": r"k_sparse_dp_fast_batch<1>"}[dom]
+                hit = [v for k, v in tj.items() if re.match(pat, k)]
+                if hit and args.dtype == "bf16" and (N, M, K, d) == (4096, 4096, 4, 1024):
+                    traffic = hit[0] * P
+            except Exception:
+                traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                               "frac": achieved / 8000.0, "traffic": None,
+                               "frac": achieved / 8000.0, "traffic": traffic,
                                "avg_launch_ms": avg_ms, "launches": launches,
                                "algorithmic_bytes_per_launch": per_launch_bytes,
                                "whole_path_input_bytes_per_pair": alg_bytes_pair,
