@@ -339,8 +339,8 @@ constexpr int TA = SVX_BC_TA, TB = SVX_BC_TB, ROWS = SVX_BC_ROWS;
 constexpr int BC_THREADS = 512;
 constexpr int BC_WAVES = BC_THREADS / 64;
 static_assert(BC_WAVES == 8, "unit -> (wave, slot) is decoded with shifts");
-constexpr int UPW = 6;                        // (type, x-tile) units per wave per pass
-constexpr int TPP = BC_WAVES * UPW / 3;       // types per pass (16)
+constexpr int UPW_FULL = 6;                   // (type, x-tile) units per wave per pass
+constexpr int TPP_FULL = BC_WAVES * UPW_FULL / 3;  // types per pass (16)
 constexpr int DUMP_UNIT = 16 * ROWS;          // floats of one unit's 16 x 48 accumulator block
 
 struct BandArgs {
@@ -418,6 +418,10 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
     using M = Mma<E>;
     constexpr int RSB = SW * 128 + 16;
     constexpr int KSB = M::KS * SW, NKB = M::NK * SW;
+    // 512-byte slabs are only used for single-layer levels (<= 2 types): one unit per wave keeps the
+    // accumulators at 12 registers so that several workgroups share a CU and hide the load latency
+    constexpr int UPW = (SW == 4) ? 1 : UPW_FULL;
+    constexpr int TPP = BC_WAVES * UPW / 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = 2 * g.W;
     const int a0 = chunk_a * TA;
@@ -491,13 +495,19 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
     for (int pass = 0; pass * TPP < ty.n; pass++) {
         const int ntp = (ty.n - pass * TPP) < TPP ? (ty.n - pass * TPP) : TPP;
         const int nunits = ntp * 3;
+        // With at most 4 units (a single alignment type: the deeper pyramid levels) two waves share a unit
+        // and split its k-steps (even / odd); the epilogue adds the two partial dumps.
+        const bool ksplit = nunits <= 4;
+        const int khalf = ksplit ? (wave >> 2) : 0;
         f32x4_t acc[UPW][3];
         int aoff[UPW], boffs[UPW];  // LDS byte offsets of the unit's x tile rows / its type's y layer
+        int uid[UPW];
 #pragma unroll
         for (int s = 0; s < UPW; s++) {
 #pragma unroll
             for (int j = 0; j < 3; j++) acc[s][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            const int u = wave + BC_WAVES * s;
+            const int u = ksplit ? (s == 0 ? (wave & 3) : nunits) : wave + BC_WAVES * s;
+            uid[s] = u;
             const int t = pass * TPP + (u < nunits ? u / 3 : 0);
             const int xt = u % 3;
             aoff[s] = ((ltx[t] - 1) * ROWS + xt * 16) * RSB + loff;
@@ -515,15 +525,25 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < UPW; s++) {
-                if (wave + BC_WAVES * s < nunits) {  // wave-uniform
+                if (uid[s] < nunits) {  // wave-uniform
                     const char* ap = slab + aoff[s];
                     const char* bp = slab + boffs[s];
+                    if (ksplit) {
 #pragma unroll
-                    for (int ks = 0; ks < NKB; ks++) {
-                        const typename M::frag fa = M::load(ap + ks * M::KSTEP_BYTES);
+                        for (int ks2 = 0; ks2 < NKB / 2; ks2++) {
+                            const int ko = (2 * ks2 + khalf) * M::KSTEP_BYTES;
+                            const typename M::frag fa = M::load(ap + ko);
 #pragma unroll
-                        for (int j = 0; j < 3; j++)
-                            M::mma(acc[s][j], fa, M::load(bp + j * 16 * RSB + ks * M::KSTEP_BYTES));
+                            for (int j = 0; j < 3; j++) M::mma(acc[s][j], fa, M::load(bp + j * 16 * RSB + ko));
+                        }
+                    } else {
+#pragma unroll
+                        for (int ks = 0; ks < NKB; ks++) {
+                            const typename M::frag fa = M::load(ap + ks * M::KSTEP_BYTES);
+#pragma unroll
+                            for (int j = 0; j < 3; j++)
+                                M::mma(acc[s][j], fa, M::load(bp + j * 16 * RSB + ks * M::KSTEP_BYTES));
+                        }
                     }
                 }
             }
@@ -542,7 +562,7 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
         for (int s0 = 0; s0 < nslots; s0 += SR) {
 #pragma unroll
             for (int s = 0; s < UPW; s++) {
-                if (s >= s0 && s < s0 + SR && wave + BC_WAVES * s < nunits) {
+                if (s >= s0 && s < s0 + SR && uid[s] < nunits) {
                     float* dw = dump + ((s - s0) * BC_WAVES + wave) * DUMP_UNIT;
 #pragma unroll
                     for (int yt = 0; yt < 3; yt++)
@@ -562,7 +582,9 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
                     float c = __builtin_inff();
                     if (c_in) {
                         const int rx = (p - 1) * ROWS + c_xloc, ry = (kx + q - 1) * ROWS + c_yloc;
-                        const float sumx = dump[(u - ulo) * DUMP_UNIT + (c_xloc & 15) * ROWS + c_yloc] * sinv[rx] * sinv[ry];
+                        float dsum = dump[(u - ulo) * DUMP_UNIT + (c_xloc & 15) * ROWS + c_yloc];
+                        if (ksplit) dsum += dump[(u - ulo + 4) * DUMP_UNIT + (c_xloc & 15) * ROWS + c_yloc];
+                        const float sumx = dsum * sinv[rx] * sinv[ry];
                         c = cost_formula(sumx, p, q, snrm[rx], snrm[ry]);
                     }
                     Fs[((size_t)c_ai * ntp + tl) * TB + c_bi] = c;
@@ -759,8 +781,10 @@ struct BandPlan {
 // single-layer levels, else 256, else 128): wider slabs mean fewer barrier rounds per workgroup.
 static int band_plan(svx_ctx* ctx, int kx, int ky, int ntypes, BandPlan* bp) {
     const int NR = (kx + ky) * ROWS;
-    const int ntp = ntypes < TPP ? ntypes : TPP;
     for (int sw = 4; sw >= 1; sw >>= 1) {
+        const int tpp = sw == 4 ? BC_WAVES / 3 : TPP_FULL;
+        const int ntp = ntypes < tpp ? ntypes : tpp;
+        if (sw == 4 && ntypes > tpp) continue;
         const BandLds L = band_lds(kx, ky, sw, ntp);
         const int npt = (NR * 8 * sw + BC_THREADS - 1) / BC_THREADS;
         if (sw == 4 && (NR > 2 * ROWS || L.total > 64 * 1024)) continue;  // 512-byte slabs: single-layer levels only

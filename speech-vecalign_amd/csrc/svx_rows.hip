@@ -66,6 +66,21 @@ struct Row {
             }
         }
     }
+    // streaming store: written once, read by a later kernel after tens of GB of other traffic
+    __device__ static __forceinline__ void storef_nt(float* v, int d, int lane, const float* x) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            int col = (c * SVX_WAVE + lane) * VEC;
+            if (col < d) {
+#pragma unroll
+                for (int q = 0; q < VEC / 4; q++) {
+                    f4 t = {x[c * VEC + 4 * q + 0], x[c * VEC + 4 * q + 1], x[c * VEC + 4 * q + 2], x[c * VEC + 4 * q + 3]};
+                    __builtin_nontemporal_store(t, reinterpret_cast<f4*>(v + col + 4 * q));
+                }
+            }
+        }
+    }
     // lane-register index e  ->  column
     __device__ static __forceinline__ int col_of(int e, int lane) {
         return ((e / VEC) * SVX_WAVE + lane) * VEC + (e % VEC);
@@ -143,7 +158,7 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
                         xs[e] = xs[e] + x[e];
                         cs[e] += xs[e];
                     }
-                    R::storef(next + (size_t)jp * d, d, lane, xs);
+                    R::storef_nt(next + (size_t)jp * d, d, lane, xs);
                 }
             }
         }
