@@ -17,6 +17,8 @@
 // (type, x-row, y-row) product as 16x16 MFMA tiles; the epilogue picks the band cells out of the
 // accumulators, applies the cost formula in double like the reference, stages the [type][a][b]
 // block in LDS and writes it out coalesced.
+#include <stdlib.h>
+
 #include "svx_common.h"
 
 namespace {
@@ -384,30 +386,32 @@ __host__ __device__ inline BandLds band_lds(int kx, int ky, int sw, int ntypes_p
     return L;
 }
 
+// `live` has bit i set when the thread's i-th piece belongs to a row the chunk really reads.  Dead rows
+// are neither loaded nor stored: an MFMA output element only depends on its own A row and B row, and
+// the epilogue never looks at elements of dead rows, so whatever the LDS holds there is harmless.
 template <typename E, int NPT, int SW>
-__device__ __forceinline__ void slab_load(uint4* pre, const char* const* rowptr, int npieces, int k0, int d, int tid) {
+__device__ __forceinline__ void slab_load(uint4* pre, const char* const* rowptr, unsigned live, int k0, int d, int tid) {
     using S = typename E::storage;
     constexpr int PPR = 8 * SW;  // 16-byte pieces per row
 #pragma unroll
     for (int i = 0; i < NPT; i++) {
         const int q = tid + i * BC_THREADS;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (q < npieces) {
+        if ((live >> i) & 1u) {
             const int r = q / PPR, p = q % PPR;
-            const char* ptr = rowptr[r];
             const int kel = k0 + p * E::VEC;
-            if (ptr != nullptr && kel < d) v = *reinterpret_cast<const uint4*>(ptr + (size_t)kel * sizeof(S));
+            if (kel < d) v = *reinterpret_cast<const uint4*>(rowptr[r] + (size_t)kel * sizeof(S));
         }
         pre[i] = v;
     }
 }
 template <int NPT, int SW>
-__device__ __forceinline__ void slab_store(const uint4* pre, char* slab, int npieces, int tid) {
+__device__ __forceinline__ void slab_store(const uint4* pre, char* slab, unsigned live, int tid) {
     constexpr int PPR = 8 * SW, RSB = SW * 128 + 16;
 #pragma unroll
     for (int i = 0; i < NPT; i++) {
         const int q = tid + i * BC_THREADS;
-        if (q < npieces) *reinterpret_cast<uint4*>(slab + (q / PPR) * RSB + (q % PPR) * 16) = pre[i];
+        if ((live >> i) & 1u) *reinterpret_cast<uint4*>(slab + (q / PPR) * RSB + (q % PPR) * 16) = pre[i];
     }
 }
 
@@ -477,6 +481,15 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
     }
     __syncthreads();
     const int loff = (lane & 15) * RSB + (int)(sizeof(S) == 4 ? 4 : 16) * (lane >> 4);
+    unsigned live = 0;
+#pragma unroll
+    for (int i = 0; i < NPT; i++) {
+        const int q = tid + i * BC_THREADS;
+        if (q < npieces && rowptr[q / (8 * SW)] != nullptr) live |= 1u << i;
+    }
+    // 16-row tiles that hold live rows: nxt x nyt of the 3 x 3 (4 of 9 for a diagonal path)
+    const int nxt = NXn <= 16 ? 1 : (NXn <= 32 ? 2 : 3);
+    const int nyt = NYn <= 16 ? 1 : (NYn <= 32 ? 2 : 3);
 
     // this thread's output cell (one per thread: TAe * TBe <= 512)
     const int ncells = TAe * TBe;
@@ -494,7 +507,7 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
 
     for (int pass = 0; pass * TPP < ty.n; pass++) {
         const int ntp = (ty.n - pass * TPP) < TPP ? (ty.n - pass * TPP) : TPP;
-        const int nunits = ntp * 3;
+        const int nunits = ntp * nxt;  // (type, live x tile)
         // With at most 4 units (a single alignment type: the deeper pyramid levels) two waves share a unit
         // and split its k-steps (even / odd); the epilogue adds the two partial dumps.
         const bool ksplit = nunits <= 4;
@@ -508,21 +521,12 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
             for (int j = 0; j < 3; j++) acc[s][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             const int u = ksplit ? (s == 0 ? (wave & 3) : nunits) : wave + BC_WAVES * s;
             uid[s] = u;
-            const int t = pass * TPP + (u < nunits ? u / 3 : 0);
-            const int xt = u % 3;
+            const int t = pass * TPP + (u < nunits ? u / nxt : 0);
+            const int xt = u % nxt;
             aoff[s] = ((ltx[t] - 1) * ROWS + xt * 16) * RSB + loff;
             boffs[s] = ((kx + lty[t] - 1) * ROWS) * RSB + loff;
         }
-        // k loop: the global loads of slab k+1 are issued before the MFMAs of slab k
-        uint4 pre[NPT];
-        slab_load<E, NPT, SW>(pre, rowptr, npieces, 0, g.d, tid);
-        __syncthreads();  // the previous pass is done with the work area
-        slab_store<NPT, SW>(pre, slab, npieces, tid);
-        __syncthreads();
-        for (int k0 = 0; k0 < g.d; k0 += KSB) {
-            const bool more = k0 + KSB < g.d;
-            if (more) slab_load<E, NPT, SW>(pre, rowptr, npieces, k0 + KSB, g.d, tid);
-            __builtin_amdgcn_sched_barrier(0);
+        auto mma_slab = [&]() {
 #pragma unroll
             for (int s = 0; s < UPW; s++) {
                 if (uid[s] < nunits) {  // wave-uniform
@@ -534,7 +538,8 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
                             const int ko = (2 * ks2 + khalf) * M::KSTEP_BYTES;
                             const typename M::frag fa = M::load(ap + ko);
 #pragma unroll
-                            for (int j = 0; j < 3; j++) M::mma(acc[s][j], fa, M::load(bp + j * 16 * RSB + ko));
+                            for (int j = 0; j < 3; j++)
+                                if (j < nyt) M::mma(acc[s][j], fa, M::load(bp + j * 16 * RSB + ko));
                         }
                     } else {
 #pragma unroll
@@ -542,14 +547,53 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
                             const typename M::frag fa = M::load(ap + ks * M::KSTEP_BYTES);
 #pragma unroll
                             for (int j = 0; j < 3; j++)
-                                M::mma(acc[s][j], fa, M::load(bp + j * 16 * RSB + ks * M::KSTEP_BYTES));
+                                if (j < nyt) M::mma(acc[s][j], fa, M::load(bp + j * 16 * RSB + ks * M::KSTEP_BYTES));
                         }
                     }
                 }
             }
-            __syncthreads();  // every wave has read this slab
-            if (more) slab_store<NPT, SW>(pre, slab, npieces, tid);
+        };
+        if constexpr (SW == 1) {
+            // 128-byte slabs: two register sets, so every global load has two slab periods to land
+            // (slab k in LDS, slab k+1 in flight in one set, slab k+2 being issued into the other)
+            uint4 preA[NPT], preB[NPT];
+            slab_load<E, NPT, SW>(preA, rowptr, live, 0, g.d, tid);
+            __syncthreads();  // the previous pass is done with the work area
+            slab_store<NPT, SW>(preA, slab, live, tid);
+            if (KSB < g.d) slab_load<E, NPT, SW>(preA, rowptr, live, KSB, g.d, tid);
             __syncthreads();
+            for (int k0 = 0; k0 < g.d; k0 += 2 * KSB) {
+                if (k0 + 2 * KSB < g.d) slab_load<E, NPT, SW>(preB, rowptr, live, k0 + 2 * KSB, g.d, tid);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_slab();
+                __syncthreads();  // every wave has read this slab
+                if (k0 + KSB < g.d) {
+                    slab_store<NPT, SW>(preA, slab, live, tid);
+                    __syncthreads();
+                    if (k0 + 3 * KSB < g.d) slab_load<E, NPT, SW>(preA, rowptr, live, k0 + 3 * KSB, g.d, tid);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_slab();
+                    __syncthreads();
+                    if (k0 + 2 * KSB < g.d) slab_store<NPT, SW>(preB, slab, live, tid);
+                    __syncthreads();
+                }
+            }
+        } else {
+            // wide slabs: the global loads of slab k+1 are issued before the MFMAs of slab k
+            uint4 pre[NPT];
+            slab_load<E, NPT, SW>(pre, rowptr, live, 0, g.d, tid);
+            __syncthreads();  // the previous pass is done with the work area
+            slab_store<NPT, SW>(pre, slab, live, tid);
+            __syncthreads();
+            for (int k0 = 0; k0 < g.d; k0 += KSB) {
+                const bool more = k0 + KSB < g.d;
+                if (more) slab_load<E, NPT, SW>(pre, rowptr, live, k0 + KSB, g.d, tid);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_slab();
+                __syncthreads();  // every wave has read this slab
+                if (more) slab_store<NPT, SW>(pre, slab, live, tid);
+                __syncthreads();
+            }
         }
         // epilogue.  Work area = Fs [ai][type][bi] followed by the accumulator dump [unit][16][48].
         // Rounds of SR unit slots: dump -> every thread looks its cell up in each dumped unit whose x tile
@@ -574,9 +618,9 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
             if (tid < ncells) {
                 const int xq = c_xloc >> 4;
                 const int ulo = s0 * BC_WAVES, uhi = (s0 + SR) * BC_WAVES < nunits ? (s0 + SR) * BC_WAVES : nunits;
-                // units of this round whose x tile holds my row: u = 3*tl + xq
-                for (int tl = (ulo - xq + 2) / 3; 3 * tl + xq < uhi; tl++) {
-                    const int u = 3 * tl + xq;
+                // units of this round whose x tile holds my row: u = nxt*tl + xq
+                for (int tl = (ulo - xq + nxt - 1) / nxt; nxt * tl + xq < uhi; tl++) {
+                    const int u = nxt * tl + xq;
                     const int t = pass * TPP + tl;
                     const int p = ltx[t], q = lty[t];
                     float c = __builtin_inff();
@@ -781,7 +825,10 @@ struct BandPlan {
 // single-layer levels, else 256, else 128): wider slabs mean fewer barrier rounds per workgroup.
 static int band_plan(svx_ctx* ctx, int kx, int ky, int ntypes, BandPlan* bp) {
     const int NR = (kx + ky) * ROWS;
+    const char* sw_env = getenv("SVX_BAND_SW");  // tuning override: widest slab to consider
+    const int sw_max = sw_env ? atoi(sw_env) : 4;
     for (int sw = 4; sw >= 1; sw >>= 1) {
+        if (sw > sw_max) continue;
         const int tpp = sw == 4 ? BC_WAVES / 3 : TPP_FULL;
         const int ntp = ntypes < tpp ? ntypes : tpp;
         if (sw == 4 && ntypes > tpp) continue;
