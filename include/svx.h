@@ -122,6 +122,12 @@ int svx_sparse_traceback(svx_ctx *ctx, const double *csum, const int32_t *xp, co
 int svx_search_path(svx_ctx *ctx, const int32_t *align, const int32_t *n_align, int upsample, int size0,
                     int size1, int32_t *path, int32_t *path_len);
 
+/* make_doc_embedding's gather (svecalign/utils/embedding_utils.py:164-201): out[r][:] = table[idx[r]][:],
+ * or zeros where idx[r] < 0 (PAD / ignored / missing / NaN candidate).  table [n_rows][d], out [n_out][d]
+ * of `dtype`; idx [n_out] int32 is the flattened [overlaps][segments] row table built on the host. */
+int svx_gather_rows(svx_ctx *ctx, const void *table, int64_t n_rows, int d, int dtype, const int32_t *idx, int64_t n_out,
+                    void *out);
+
 /* ---- the whole of dp_utils.vecalign() for a batch of document pairs -------------------- */
 
 typedef struct svx_align_params {

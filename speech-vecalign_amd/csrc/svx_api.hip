@@ -344,6 +344,14 @@ int svx_search_path(svx_ctx* ctx, const int32_t* align, const int32_t* n_align, 
     return svxl_search_path(ctx, align, n_align, upsample, size0, size1, path, size0 + size1 + 4, path_len);
 }
 
+int svx_gather_rows(svx_ctx* ctx, const void* table, int64_t n_rows, int d, int dtype, const int32_t* idx, int64_t n_out, void* out) {
+    NEED(ctx, ctx && table && idx && out, "svx_gather_rows: null argument");
+    NEED(ctx, dtype == SVX_F32 || dtype == SVX_F16 || dtype == SVX_BF16, "svx_gather_rows: unknown dtype %d", dtype);
+    int rc = check_dim(ctx, d);
+    if (rc) return rc;
+    return svxl_gather_rows(ctx, table, n_rows, d * (dtype == SVX_F32 ? 4 : 2), idx, n_out, out);
+}
+
 int svx_num_levels(int n, int m, int max_size_full_dp) {
     long long s0 = n, s1 = m, lim = (long long)max_size_full_dp * max_size_full_dp;
     int depth = 0;

@@ -412,6 +412,21 @@ __global__ __launch_bounds__(256) void k_rownorms_plain(const float* vecs, int64
     }
 }
 
+// Candidate-tensor assembly (svecalign/utils/embedding_utils.py:135-203): out[r] = table[idx[r]], or an
+// all-zero row where idx[r] < 0 (PAD / ignored / missing / NaN candidate).  16 bytes per lane.
+__global__ __launch_bounds__(256) void k_gather_rows(const uint4* __restrict__ table, const int* __restrict__ idx, long long n_out,
+                                                     int row_pieces, long long n_rows, uint4* __restrict__ out) {
+    const long long total = n_out * row_pieces;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / row_pieces;
+        const int p = (int)(i - r * row_pieces);
+        const int src = idx[r];
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (src >= 0 && src < n_rows) v = table[(long long)src * row_pieces + p];
+        out[i] = v;
+    }
+}
+
 inline int nch_f32(int d) {
     int c = (d + 255) / 256;
     return c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : 8;
@@ -526,5 +541,16 @@ int svxl_pyramid_level(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int l
     }
 #undef LAUNCH
     SVX_LAUNCH_CHECK(ctx, "k_pyramid");
+    return SVX_OK;
+}
+
+int svxl_gather_rows(svx_ctx* ctx, const void* table, long long n_rows, int row_bytes, const int* idx, long long n_out, void* out) {
+    if (n_out <= 0) return SVX_OK;
+    const int pieces = row_bytes / 16;
+    long long nb = (n_out * pieces + 255) / 256;
+    if (nb > 65535) nb = 65535;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)nb), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4*>(table), idx, n_out,
+                       pieces, n_rows, reinterpret_cast<uint4*>(out));
+    SVX_LAUNCH_CHECK(ctx, "k_gather_rows");
     return SVX_OK;
 }

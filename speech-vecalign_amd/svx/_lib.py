@@ -71,6 +71,7 @@ _SIGS = {
     "svx_dense_traceback": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "svx_sparse_traceback": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "svx_search_path": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "svx_gather_rows": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_i64, c_vp]),
     "svx_num_levels": (c_int, [c_int, c_int, c_int]),
     "svx_knob_count": (c_i64, [c_int, c_int, c_int]),
     "svx_align_batch": (c_int, [c_vp, ctypes.POINTER(AlignParams), ctypes.POINTER(Pair), c_int]),

@@ -102,16 +102,20 @@ def candidate_index_table(sent2id: dict, lines: List[str], max_overlaps: int,
 
 
 def gather_candidates(line_embeddings, table: np.ndarray, device=None):
-    """Device gather: out[j, i] = line_embeddings[table[j, i]] or 0 -> torch tensor [K, N, d]."""
+    """Device gather (svx_gather_rows): out[j, i] = line_embeddings[table[j, i]] or 0 -> torch tensor [K, N, d]."""
+    import ctypes
     from .. import _lib
     ctx = _lib.context(0 if device is None else device)
     t = ctx.torch
-    emb = line_embeddings if hasattr(line_embeddings, "data_ptr") else t.from_numpy(np.ascontiguousarray(line_embeddings))
-    emb = emb.to(ctx.tdev)
-    idx = t.from_numpy(np.ascontiguousarray(table)).to(ctx.tdev).long()
-    out = emb[idx.clamp(min=0)]
-    out[idx < 0] = 0
-    return out.contiguous()
+    # (np.array copies: the file readers hand out read-only memory maps)
+    emb = line_embeddings if hasattr(line_embeddings, "data_ptr") else t.from_numpy(np.array(line_embeddings))
+    emb = emb.to(ctx.tdev).contiguous()
+    dt = {t.float32: _lib.SVX_F32, t.float16: _lib.SVX_F16, t.bfloat16: _lib.SVX_BF16}[emb.dtype]
+    idx = t.from_numpy(np.ascontiguousarray(table, dtype=np.int32)).to(ctx.tdev)
+    out = t.empty(tuple(table.shape) + (emb.shape[1],), dtype=emb.dtype, device=ctx.tdev)
+    ctx.check(ctx.lib.svx_gather_rows(ctx.h, ctypes.c_void_p(emb.data_ptr()), int(emb.shape[0]), int(emb.shape[1]), dt,
+                                      ctypes.c_void_p(idx.data_ptr()), int(idx.numel()), ctypes.c_void_p(out.data_ptr())))
+    return out
 
 
 def make_doc_embedding(sent2id: dict, line_embeddings: np.ndarray, lines: List[str], max_overlaps: int,

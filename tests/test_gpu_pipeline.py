@@ -144,3 +144,47 @@ def test_degenerate_documents(orc):
         assert np.abs(got[0]['alignment_scores'] - ref[0]['alignment_scores']).max() < SCORE_TOL
     with pytest.raises(Exception, match=r"4 x overlaps requrested \(via alignment_types\), but vecs0 only has 2"):
         dp_utils.vecalign(*make_pair(30, 30, 2, 64, 5), alignment_types(5), 0.2, 7, 300, 20000, 100)
+
+
+def test_sakoe_chiba_band_vs_oracle(orc):
+    """BASELINE configs[3] semantics at a size the oracle finishes in seconds: straight-diagonal search
+    path, wide band (B = 96 > 64: generic DP kernel, six band-cell chunks per path chunk)."""
+    from svx.vecalign import dp_utils
+    N, M, K, W = 900, 840, 3, 48
+    v0, v1 = make_pair(N, M, K, 64, 91, deletions=25)
+    types = alignment_types(4)
+    a, b = v0.copy(), v1.copy()
+    orc.make_norm1(a)
+    orc.make_norm1(b)
+    rs = np.random.RandomState(17)
+    n0, n1 = orc.compute_norms(a, b, 100, rs), orc.compute_norms(b, a, 100, rs)
+    pen, _ = orc.make_del_penalty(a[0], b[0], n0[0], n1[0], 20000, 0.2, rs)
+    path = orc.search_path([(list(range(N)), list(range(M)))], False, N, M)
+    f, bo = orc.make_sparse_costs(a, b, n0, n1, path, types, W)
+    al_o, sc_o = orc.sparse_traceback(*orc.sparse_dp(f, bo, types, pen, N, M), N, M)
+    np.random.seed(17)
+    al_g, sc_g = dp_utils.align_band(v0, v1, types, 0.2, W, 20000, 100)
+    assert al_g == al_o
+    assert np.abs(sc_g - sc_o).max() < SCORE_TOL
+
+
+def test_ragged_batch_up_to_8192(orc):
+    """BASELINE configs[2] shape: one batch of pairs with N, M drawn from [512, 8192]; every pair is
+    checked for full monotone coverage, the largest one against the oracle."""
+    import torch
+    from svx.vecalign import dp_utils
+    rs = np.random.RandomState(3)
+    shapes = [(int(rs.randint(512, 8193)), int(rs.randint(512, 8193))) for _ in range(5)] + [(8192, 8000)]
+    types = alignment_types(5)
+    docs, hosts = [], []
+    for i, (n, m) in enumerate(shapes):
+        v0, v1 = make_pair(n, m, 4, 64, 200 + i)
+        v0, v1 = round_bf16(v0), round_bf16(v1)
+        hosts.append((v0, v1))
+        docs.append((torch.from_numpy(v0).cuda().bfloat16(), torch.from_numpy(v1).cuda().bfloat16()))
+    res = dp_utils.align_batch(docs, types, 0.2, 7, 300, 20000, 100, rngs=[np.random.RandomState(i) for i in range(len(docs))])
+    for (n, m), r in zip(shapes, res):
+        assert [x for al in r[0] for x in al[0]] == list(range(n)) and [y for al in r[0] for y in al[1]] == list(range(m))
+    i = len(shapes) - 1
+    ref = orc.vecalign(hosts[i][0].copy(), hosts[i][1].copy(), types, 0.2, 7, 300, 20000, 100, rng=np.random.RandomState(i))
+    assert res[i][0] == ref[0]['final_alignments'] and np.abs(res[i][1] - ref[0]['alignment_scores']).max() < SCORE_TOL
