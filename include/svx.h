@@ -128,6 +128,32 @@ int svx_search_path(svx_ctx *ctx, const int32_t *align, const int32_t *n_align, 
 int svx_gather_rows(svx_ctx *ctx, const void *table, int64_t n_rows, int d, int dtype, const int32_t *idx, int64_t n_out,
                     void *out);
 
+/* ---- global margin scoring of the mined alignments (next row after the alignment path) ---
+ * svecalign/postprocess/score_align.py:118-161 (compute_sim_with_nonflat_idx) and the index side of
+ * svecalign/postprocess/prep_index.py:153-185 (populate_index), for an exact ("Flat") database held in
+ * HBM as unit-norm fp16 / bf16 rows -- the storage of the reference's faiss GPU index with gpu_type
+ * "fp16-shard" (score_align.py:48-50). */
+
+#define SVX_MARGIN_RATIO 0
+#define SVX_MARGIN_DISTANCE 1
+
+/* populate_index: out[i] = rows[i] / |rows[i]| (faiss.normalize_L2, prep_index.py:180) stored as
+ * out_dtype (SVX_F16 | SVX_BF16).  rows [n][d] of `dtype`; d a multiple of 32, at most 1024. */
+int svx_unit_rows(svx_ctx *ctx, const void *rows, int dtype, int64_t n, int d, void *out, int out_dtype);
+
+/* index.search(x, k) + the mean over the k neighbours (score_align.py:137-148), exact search:
+ * mean_sim[i] = mean of the k largest <q_i / |q_i|, db_j>, j < n_db  (= (2 - mean L2^2) / 2 of the
+ * reference for unit rows).  queries [n][d] of q_dtype are normalised on the fly (not in place) and
+ * rounded to db_dtype for the MFMA, accumulation in fp32.  db [n_db][d] fp16 / bf16, n_db >= k,
+ * 1 <= k <= 64. */
+int svx_knn_mean_sim(svx_ctx *ctx, const void *queries, int q_dtype, int64_t n, const void *db, int db_dtype,
+                     int64_t n_db, int d, int k, float *mean_sim);
+
+/* score_align.py:151-160: scores[i] = <x_i/|x_i|, y_i/|y_i|> / ((mean_xy[i] + mean_yx[i]) / 2)
+ * (SVX_MARGIN_RATIO) or minus it (SVX_MARGIN_DISTANCE).  x, y [n][d] of `dtype`. */
+int svx_margin_scores(svx_ctx *ctx, const void *x, const void *y, int dtype, int64_t n, int d, const float *mean_xy,
+                      const float *mean_yx, int margin, float *scores);
+
 /* ---- the whole of dp_utils.vecalign() for a batch of document pairs -------------------- */
 
 typedef struct svx_align_params {

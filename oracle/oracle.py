@@ -326,3 +326,58 @@ def vecalign(vecs0, vecs1, final_alignment_types, del_percentile_frac, width_ove
         st[akey], st['alignment_scores'] = sparse_traceback(st['a_b_csum'], st['a_b_xp'], st['a_b_yp'],
                                                             st['new_b_offset'], st['size0'], st['size1'])
     return stack
+
+
+# ---------------------------------------------------------------------------------------------
+# Margin scoring of the mined alignments (the row after the alignment path).
+#   /root/reference/svecalign/postprocess/score_align.py:118-161  compute_sim_with_nonflat_idx
+# The reference searches faiss indexes (third-party, absent here: faiss-gpu, no version pinned in the
+# reference's README); for the Flat index type the search is exact brute force over the stored
+# unit-norm rows, which is what this restates.  Pinned by the reference's own shipped example:
+# tests/golden/margin_example.npz holds the rows of example/voxpopuli/*_embed_indexes/en-de/*/
+# Flat.populate.idx and the scores of example/voxpopuli/*_margin/en-de/*.txt; this function reproduces
+# them to 1.3e-4 (the example was produced by faiss' fp16 GPU search, tests/test_oracle_golden.py).
+def round_storage(a, storage):
+    """fp32 -> the database's storage type -> fp32 (round to nearest even)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if storage == "fp32":
+        return a
+    if storage == "fp16":
+        return a.astype(np.float16).astype(np.float32)
+    if storage == "bf16":
+        u = a.view(np.uint32).astype(np.uint64)
+        u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+        return u.astype(np.uint32).view(np.float32)
+    raise ValueError(storage)
+
+
+def normalize_l2(x):
+    """faiss.normalize_L2 (score_align.py:133-134): x * (1 / sqrt(sum x^2)) in fp32, zero rows untouched."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    ss = np.einsum("ij,ij->i", x, x, dtype=np.float32)
+    with np.errstate(divide="ignore"):
+        inv = np.where(ss > 0, np.float32(1.0) / np.sqrt(ss, dtype=np.float32), np.float32(0.0)).astype(np.float32)
+    return x * inv[:, None]
+
+
+def knn_mean_sim(queries, db, k, storage="fp16"):
+    """index.search + mean (score_align.py:137-148) for unit rows: mean of the k largest <q, db_j>.
+    `db` holds stored (already rounded) unit rows; the queries are normalised and rounded the same way."""
+    q = round_storage(normalize_l2(queries), storage).astype(np.float64)
+    sims = q @ np.asarray(db, dtype=np.float64).T
+    top = np.partition(sims, sims.shape[1] - k, axis=1)[:, sims.shape[1] - k:]
+    return top.mean(axis=1).astype(np.float32)
+
+
+def margin_scores(x, y, db_x, db_y, k=16, margin="ratio", storage="fp16"):
+    """score_align.py:124-161.  db_x / db_y: the stored rows of the source / target index."""
+    xn, yn = normalize_l2(x), normalize_l2(y)
+    mean_xy = knn_mean_sim(x, db_y, k, storage)
+    mean_yx = knn_mean_sim(y, db_x, k, storage)
+    a = np.einsum("ij,ij->i", xn, yn, dtype=np.float32)
+    b = (mean_xy + mean_yx) / np.float32(2)
+    if margin == "ratio":
+        return (a / b).astype(np.float32)
+    if margin == "distance":
+        return (a - b).astype(np.float32)
+    raise ValueError(f"Wrong margin type: {margin}")

@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libsvx.so")
 SVX_F32, SVX_F16, SVX_BF16 = 0, 1, 2
 SVX_MAX_TYPES = 128
 SVX_MAX_LEVELS = 16
+SVX_MARGIN_RATIO, SVX_MARGIN_DISTANCE = 0, 1
 
 SVX_OK, SVX_ERR_ARG, SVX_ERR_OVERLAPS, SVX_ERR_HIP, SVX_ERR_TRACEBACK = 0, 1, 2, 3, 4
 SVX_ERR_NOMEM, SVX_ERR_EXTEND, SVX_ERR_PATH, SVX_ERR_BP = 5, 6, 7, 8
@@ -72,6 +73,9 @@ _SIGS = {
     "svx_sparse_traceback": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "svx_search_path": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "svx_gather_rows": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_i64, c_vp]),
+    "svx_unit_rows": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_int]),
+    "svx_knn_mean_sim": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_int, c_int, c_vp]),
+    "svx_margin_scores": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_int, c_vp]),
     "svx_num_levels": (c_int, [c_int, c_int, c_int]),
     "svx_knob_count": (c_i64, [c_int, c_int, c_int]),
     "svx_align_batch": (c_int, [c_vp, ctypes.POINTER(AlignParams), ctypes.POINTER(Pair), c_int]),

@@ -135,8 +135,40 @@ def gen_example(ref):
     print("example_trim:", sum(os.path.getsize(os.path.join(od, f)) for f in os.listdir(od)) // 1024, "KiB")
 
 
+def gen_margin(ref_root):
+    """The reference's shipped margin-scoring example as data: the rows of its two populated Flat indexes
+    (exactly fp16-representable, stored as fp16) and the third field of its margin file.  The aligned
+    embeddings of the example ARE the index rows, in file order (one document pair in the corpus)."""
+    import struct
+    ex = os.path.join(ref_root, "example", "voxpopuli")
+    stem = "20180313-0900-PLENARY-15"
+
+    def flat_rows(path):
+        b = open(path, "rb").read()
+        assert b[:4] == b"IxF2"
+        d, ntotal = struct.unpack("<iq", b[4:16])
+        rows = np.frombuffer(b, dtype="<f4", count=ntotal * d, offset=45).reshape(ntotal, d)
+        assert np.array_equal(rows.astype(np.float16).astype(np.float32), rows)
+        return rows.astype(np.float16)
+    idx = os.path.join(ex, "align_0.7_clean_cat3_min1s_embed_indexes", "en-de")
+    lines = open(os.path.join(ex, "align_0.7_clean_cat3_min1s_margin", "en-de", f"{stem}_en-{stem}_de.txt")).read().splitlines()
+    out = {"db_src": flat_rows(os.path.join(idx, "en", "Flat.populate.idx")),
+           "db_tgt": flat_rows(os.path.join(idx, "de", "Flat.populate.idx")),
+           "expected": np.array([float(l.split(":")[2]) for l in lines], dtype=np.float32)}
+    assert out["db_src"].shape[0] == out["db_tgt"].shape[0] == out["expected"].shape[0]
+    np.savez_compressed(os.path.join(HERE, "margin_example.npz"), **out)
+    print("margin_example.npz:", os.path.getsize(os.path.join(HERE, "margin_example.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    ref = ref_loader.load()
-    gen_ops(ref)
-    gen_pipeline(ref)
-    gen_example(ref)
+    what = sys.argv[1:] or ["ops", "pipeline", "example", "margin"]
+    if "margin" in what:
+        gen_margin(ref_loader.REF_ROOT)
+    if set(what) - {"margin"}:
+        ref = ref_loader.load()
+        if "ops" in what:
+            gen_ops(ref)
+        if "pipeline" in what:
+            gen_pipeline(ref)
+        if "example" in what:
+            gen_example(ref)
