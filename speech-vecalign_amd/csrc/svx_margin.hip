@@ -55,24 +55,130 @@ __device__ __forceinline__ void mma16(f32x4_t& acc, const uint4& a, const uint4&
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
 }
 
-#define KNN_PF 16  // 16-byte pieces of a database tile staged by one thread
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
-// Tile t of the database -> registers.  Rows past the end of the database are read from its last row and
-// masked out at the top-k update.  loff[i] bits 20..24 hold the piece's row inside the tile.
-__device__ __forceinline__ void knn_fetch(u32x4_t (&pf)[KNN_PF], const uint16_t* __restrict__ db, long t, long N, int d,
-                                          const int (&gcol)[KNN_PF], const int (&loff)[KNN_PF]) {
-    const long row0 = t * KNN_DT;
+// Tile t of the database -> LDS, with no register stop-over (global_load_lds_dwordx4: every lane names its
+// own source address, the wave's 64 x 16 B land back to back at a wave-uniform LDS address = half a row).
+// Wave w brings rows 8w .. 8w+7.  Rows past the end of the database are read from its last row and masked
+// out at the top-k update; lanes past the row's d elements stay idle, so those LDS columns keep their zeros.
+__device__ __forceinline__ void knn_fetch(const uint16_t* __restrict__ db, long t, long N, int d, char* buf, int w, int lane) {
 #pragma unroll
-    for (int i = 0; i < KNN_PF; i++) {
-        long r = row0 + ((loff[i] >> 20) & 31);
-        r = r < N ? r : N - 1;
-        pf[i] = *reinterpret_cast<const u32x4_t*>(db + r * (long)d + gcol[i]);
+    for (int i = 0; i < KNN_DT / 4; i++) {
+        const int r = w * (KNN_DT / 4) + i;
+        long gr = t * KNN_DT + r;
+        gr = gr < N ? gr : N - 1;
+        const char* src = reinterpret_cast<const char*>(db + gr * (long)d) + lane * 16;
+        char* dst = buf + r * KNN_RS;
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+            if (h * 1024 + lane * 16 < 2 * d)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + h * 1024), (lptr_t)(dst + h * 1024), 16, 0, 0);
     }
 }
-__device__ __forceinline__ void knn_stash(const u32x4_t (&pf)[KNN_PF], char* buf, const int (&loff)[KNN_PF]) {
+
+// One database tile: 16 RPW x 32 similarities per wave on the matrix cores, then the per-row top-k update.
+// `cur` holds tile t; Sw / heap / thr are this wave's scratch rows, the kept lists and their minima.
+template <bool BF, int RPW>
+__device__ __forceinline__ void knn_tile(const char* cur, long t, long N, int k, int k4, int hs, const uint4 (&qf)[RPW][KNN_KSTEPS],
+                                         float* Sw, float* heap, float* thr, int w, int lane) {
+    constexpr int rs = KNN_RS;
+    const int lr = lane & 15, lg = lane >> 4;
+    const char* buf = cur;
+    f32x4_t acc[RPW][2];
 #pragma unroll
-    for (int i = 0; i < KNN_PF; i++)
-        if (loff[i] >= 0) *reinterpret_cast<u32x4_t*>(buf + (loff[i] & 0xfffff)) = pf[i];
+    for (int b = 0; b < RPW; b++) acc[b][0] = acc[b][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const char* bp = buf + lr * rs + 16 * lg;
+    // B-fragments are read two k-steps ahead of the MFMAs that use them (one wave per SIMD: nothing
+    // else hides the LDS latency)
+    uint4 bq[3][2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        bq[s][0] = *reinterpret_cast<const uint4*>(bp + 64 * s);
+        bq[s][1] = *reinterpret_cast<const uint4*>(bp + 16 * rs + 64 * s);
+    }
+#pragma unroll
+    for (int s = 0; s < KNN_KSTEPS; s++) {
+        if (s + 2 < KNN_KSTEPS) {
+            bq[(s + 2) % 3][0] = *reinterpret_cast<const uint4*>(bp + 64 * (s + 2));
+            bq[(s + 2) % 3][1] = *reinterpret_cast<const uint4*>(bp + 16 * rs + 64 * (s + 2));
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of this k-step's MFMAs
+#pragma unroll
+        for (int b = 0; b < RPW; b++) {
+            mma16<BF>(acc[b][0], qf[b][s], bq[s % 3][0]);
+            mma16<BF>(acc[b][1], qf[b][s], bq[s % 3][1]);
+        }
+    }
+    // ---- top-k update.  acc[b][j][r] = <query 16(w RPW + b) + 4 lg + r, database row 32 t + 16 j + lr>
+    const bool c0 = t * KNN_DT + lr < N, c1 = t * KNN_DT + 16 + lr < N;
+    // bal[b][j][r]: lanes whose value beats the current k-th best of its row (rare after the first tiles)
+    unsigned long long bal[RPW][2][4];
+    unsigned long long any = 0;
+#pragma unroll
+    for (int b = 0; b < RPW; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float th = thr[(w * RPW + b) * 16 + 4 * lg + r];
+            bal[b][0][r] = __ballot(c0 && acc[b][0][r] > th);
+            bal[b][1][r] = __ballot(c1 && acc[b][1][r] > th);
+            any |= bal[b][0][r] | bal[b][1][r];
+        }
+    if (any != 0) {  // wave-uniform
+#pragma unroll
+        for (int b = 0; b < RPW; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float* row = Sw + (b * 16 + 4 * lg + r) * KNN_SPAD;
+                row[lr] = acc[b][0][r];
+                row[16 + lr] = acc[b][1][r];
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 16 * RPW) {
+            // the owner lane of a row walks only that row's flagged columns
+            const int ob = lane >> 4, orr = lane & 3, sh = 16 * ((lane & 15) >> 2);
+            unsigned long long m0 = 0, m1 = 0;
+#pragma unroll
+            for (int b = 0; b < RPW; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (ob == b && orr == r) { m0 = bal[b][0][r]; m1 = bal[b][1][r]; }
+            unsigned cols = (unsigned)((m0 >> sh) & 0xffffu) | ((unsigned)((m1 >> sh) & 0xffffu) << 16);
+            if (cols) {
+                const int qi = w * RPW * 16 + lane;
+                float* h = heap + qi * hs;
+                float tr = thr[qi];
+                const float* row = Sw + lane * KNN_SPAD;
+                while (cols) {
+                    const int c = __builtin_ctz(cols);
+                    cols &= cols - 1;
+                    const float v = row[c];
+                    if (v > tr) {
+                        // replace the smallest kept value; the new threshold is the smaller of v and the runner-up
+                        int at = 0;
+                        float lo = INFINITY, lo2 = INFINITY;
+#pragma unroll 4
+                        for (int j = 0; j < k4; j += 4) {
+                            const f32x4_t e = *reinterpret_cast<const f32x4_t*>(h + j);
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                if (e[u] < lo) { lo2 = lo; lo = e[u]; at = j + u; }
+                                else if (e[u] < lo2) lo2 = e[u];
+                            }
+                        }
+                        h[at] = v;
+                        tr = fminf(v, lo2);
+                    }
+                }
+                thr[qi] = tr;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 }
 
 // One workgroup = 4 waves x RPW blocks of 16 query rows.  LDS: two database tiles [KNN_DT][2d + 16 B],
@@ -81,16 +187,18 @@ template <bool BF, typename QE, int RPW>
 __global__ __launch_bounds__(256, 1) void k_knn_mean(const typename QE::storage* __restrict__ q, long n,
                                                      const uint16_t* __restrict__ db, long N, int d, int k,
                                                      float* __restrict__ out) {
+    // Two tile buffers as two LDS objects: the compiler then knows that the ds_reads of one never touch the
+    // tile an LDS-DMA is still filling, and does not drain the DMA (s_waitcnt vmcnt(0)) in front of them.
+    __shared__ __attribute__((aligned(16))) char tile0[KNN_DT * KNN_RS];
+    __shared__ __attribute__((aligned(16))) char tile1[KNN_DT * KNN_RS];
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QT = 64 * RPW;
-    constexpr int rs = KNN_RS;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
-    char* tiles = smem;
-    float* S = reinterpret_cast<float*>(smem + 2 * KNN_DT * rs);  // [4][16 * RPW][KNN_SPAD]
-    float* heap = S + 4 * 16 * RPW * KNN_SPAD;                   // [QT][k + 1]
-    float* thr = heap + QT * (k + 1);                            // [QT]
-    const int hs = k + 1;
+    float* S = reinterpret_cast<float*>(smem);                   // [4][16 * RPW][KNN_SPAD]
+    const int k4 = (k + 3) & ~3, hs = k4 + 4;                    // list stride: 16-byte groups + one group of padding
+    float* heap = S + 4 * 16 * RPW * KNN_SPAD;                   // [QT][hs]: k kept values, +INF in the slots past k
+    float* thr = heap + QT * hs;                                 // [QT]
 
     // ---- query rows -> unit norm (faiss.normalize_L2, score_align.py:133-134) -> MFMA A-fragments
     uint4 qf[RPW][KNN_KSTEPS];
@@ -128,124 +236,26 @@ __global__ __launch_bounds__(256, 1) void k_knn_mean(const typename QE::storage*
             qf[b][s] = v;
         }
     }
-    for (int i = tid; i < 2 * KNN_DT * rs / 16; i += 256) reinterpret_cast<uint4*>(tiles)[i] = make_uint4(0, 0, 0, 0);
-    for (int i = tid; i < QT * hs; i += 256) heap[i] = -INFINITY;
+    for (int i = tid; i < KNN_DT * KNN_RS / 16; i += 256) {
+        reinterpret_cast<uint4*>(tile0)[i] = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4*>(tile1)[i] = make_uint4(0, 0, 0, 0);
+    }
+    for (int i = tid; i < QT * hs; i += 256) heap[i] = (i % hs) < k ? -INFINITY : INFINITY;
     for (int i = tid; i < QT; i += 256) thr[i] = -INFINITY;
 
-    // ---- database tile staging: this thread's 16-byte pieces (same positions in every tile)
-    const int ppr = d >> 3;              // pieces per row
-    const int npieces = KNN_DT * ppr;    // <= 4096
-    constexpr int PF = KNN_PF;
-    int gcol[PF], loff[PF];  // loff < 0: no such piece (d < 1024)
-#pragma unroll
-    for (int i = 0; i < PF; i++) {
-        const int p = tid + 256 * i;
-        const int r = p / ppr, c = p - r * ppr;
-        gcol[i] = p < npieces ? c * 8 : 0;
-        loff[i] = p < npieces ? ((r * rs + c * 16) | (r << 20)) : -1;  // tile row kept in bits 20..24
-    }
     const long ntiles = (N + KNN_DT - 1) / KNN_DT;
-    u32x4_t pf[PF];
-    if (ntiles > 0) knn_fetch(pf, db, 0, N, d, gcol, loff);
     __syncthreads();  // (tiles cleared)
-    if (ntiles > 0) knn_stash(pf, tiles, loff);
+    if (ntiles > 0) knn_fetch(db, 0, N, d, tile0, w, lane);
     __syncthreads();
 
     float* Sw = S + w * 16 * RPW * KNN_SPAD;
-    for (long t = 0; t < ntiles; t++) {
-        const char* buf = tiles + (t & 1) * KNN_DT * rs;
-        if (t + 1 < ntiles) knn_fetch(pf, db, t + 1, N, d, gcol, loff);
-        f32x4_t acc[RPW][2];
-#pragma unroll
-        for (int b = 0; b < RPW; b++) acc[b][0] = acc[b][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        const char* bp = buf + lr * rs + 16 * lg;
-        // B-fragments are read two k-steps ahead of the MFMAs that use them (one wave per SIMD: nothing
-        // else hides the LDS latency)
-        uint4 bq[3][2];
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-            bq[s][0] = *reinterpret_cast<const uint4*>(bp + 64 * s);
-            bq[s][1] = *reinterpret_cast<const uint4*>(bp + 16 * rs + 64 * s);
-        }
-#pragma unroll
-        for (int s = 0; s < KNN_KSTEPS; s++) {
-            if (s + 2 < KNN_KSTEPS) {
-                bq[(s + 2) % 3][0] = *reinterpret_cast<const uint4*>(bp + 64 * (s + 2));
-                bq[(s + 2) % 3][1] = *reinterpret_cast<const uint4*>(bp + 16 * rs + 64 * (s + 2));
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of this k-step's MFMAs
-#pragma unroll
-            for (int b = 0; b < RPW; b++) {
-                mma16<BF>(acc[b][0], qf[b][s], bq[s % 3][0]);
-                mma16<BF>(acc[b][1], qf[b][s], bq[s % 3][1]);
-            }
-        }
-        // ---- top-k update.  acc[b][j][r] = <query 16(w RPW + b) + 4 lg + r, database row 32 t + 16 j + lr>
-        const bool c0 = t * KNN_DT + lr < N, c1 = t * KNN_DT + 16 + lr < N;
-        // bal[b][j][r]: lanes whose value beats the current k-th best of its row (rare after the first tiles)
-        unsigned long long bal[RPW][2][4];
-        unsigned long long any = 0;
-#pragma unroll
-        for (int b = 0; b < RPW; b++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float th = thr[(w * RPW + b) * 16 + 4 * lg + r];
-                bal[b][0][r] = __ballot(c0 && acc[b][0][r] > th);
-                bal[b][1][r] = __ballot(c1 && acc[b][1][r] > th);
-                any |= bal[b][0][r] | bal[b][1][r];
-            }
-        if (any != 0) {  // wave-uniform
-#pragma unroll
-            for (int b = 0; b < RPW; b++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float* row = Sw + (b * 16 + 4 * lg + r) * KNN_SPAD;
-                    row[lr] = acc[b][0][r];
-                    row[16 + lr] = acc[b][1][r];
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < 16 * RPW) {
-                // the owner lane of a row walks only that row's flagged columns
-                const int ob = lane >> 4, orr = lane & 3, sh = 16 * ((lane & 15) >> 2);
-                unsigned long long m0 = 0, m1 = 0;
-#pragma unroll
-                for (int b = 0; b < RPW; b++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        if (ob == b && orr == r) { m0 = bal[b][0][r]; m1 = bal[b][1][r]; }
-                unsigned cols = (unsigned)((m0 >> sh) & 0xffffu) | ((unsigned)((m1 >> sh) & 0xffffu) << 16);
-                if (cols) {
-                    const int qi = w * RPW * 16 + lane;
-                    float* h = heap + qi * hs;
-                    float tr = thr[qi];
-                    const float* row = Sw + lane * KNN_SPAD;
-                    while (cols) {
-                        const int c = __builtin_ctz(cols);
-                        cols &= cols - 1;
-                        const float v = row[c];
-                        if (v > tr) {
-                            // replace the smallest kept value; the new threshold is the smaller of v and the runner-up
-                            int at = 0;
-                            float lo = h[0], lo2 = INFINITY;
-                            for (int j = 1; j < k; j++) {
-                                const float e = h[j];
-                                if (e < lo) { lo2 = lo; lo = e; at = j; }
-                                else if (e < lo2) lo2 = e;
-                            }
-                            h[at] = v;
-                            tr = fminf(v, lo2);
-                        }
-                    }
-                    thr[qi] = tr;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        if (t + 1 < ntiles) knn_stash(pf, tiles + ((t + 1) & 1) * KNN_DT * rs, loff);
+    for (long t = 0; t < ntiles; t += 2) {
+        if (t + 1 < ntiles) knn_fetch(db, t + 1, N, d, tile1, w, lane);
+        knn_tile<BF, RPW>(tile0, t, N, k, k4, hs, qf, Sw, heap, thr, w, lane);
+        __syncthreads();
+        if (t + 1 >= ntiles) break;
+        if (t + 2 < ntiles) knn_fetch(db, t + 2, N, d, tile0, w, lane);
+        knn_tile<BF, RPW>(tile1, t + 1, N, k, k4, hs, qf, Sw, heap, thr, w, lane);
         __syncthreads();
     }
     if (lane < 16 * RPW) {
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(256) void k_unit_rows(const typename QE::storage* _
 
 // ------------------------------------------------------------------------------------ launchers
 static size_t knn_smem(int d, int k, int rpw) {
-    return (size_t)2 * KNN_DT * KNN_RS + (size_t)4 * 16 * rpw * KNN_SPAD * 4 + (size_t)64 * rpw * (k + 2) * 4;
+    return (size_t)4 * 16 * rpw * KNN_SPAD * 4 + (size_t)64 * rpw * (((k + 3) & ~3) + 5) * 4;
 }
 
 template <bool BF, typename QE, int RPW>
@@ -346,7 +356,7 @@ static int launch_knn(svx_ctx* ctx, const void* q, long n, const void* db, long 
 template <bool BF, typename QE>
 static int launch_knn_rpw(svx_ctx* ctx, const void* q, long n, const void* db, long N, int d, int k, float* out) {
     // two 16-row blocks per wave halve the LDS reads per MFMA; worth it once the grid still fills the chip
-    if (n >= 128 * 256 && knn_smem(d, k, 2) <= 160 * 1024) return launch_knn<BF, QE, 2>(ctx, q, n, db, N, d, k, out);
+    if (n >= 128 * 256 && knn_smem(d, k, 2) + 2 * KNN_DT * KNN_RS <= 160 * 1024) return launch_knn<BF, QE, 2>(ctx, q, n, db, N, d, k, out);
     return launch_knn<BF, QE, 1>(ctx, q, n, db, N, d, k, out);
 }
 
