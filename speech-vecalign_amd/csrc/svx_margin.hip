@@ -9,6 +9,7 @@
 // as MFMA A-fragments for the whole sweep, database tiles stream through LDS once per workgroup and the
 // similarity matrix never exists in memory.
 #include <math.h>
+#include <stdlib.h>
 
 #include "svx_common.h"
 
@@ -58,39 +59,84 @@ __device__ __forceinline__ void mma16(f32x4_t& acc, const uint4& a, const uint4&
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// Tile t of the database -> LDS, with no register stop-over (global_load_lds_dwordx4: every lane names its
-// own source address, the wave's 64 x 16 B land back to back at a wave-uniform LDS address = half a row).
-// Wave w brings rows 8w .. 8w+7.  Rows past the end of the database are read from its last row and masked
-// out at the top-k update; lanes past the row's d elements stay idle, so those LDS columns keep their zeros.
-__device__ __forceinline__ void knn_fetch(const uint16_t* __restrict__ db, long t, long N, int d, char* buf, int w, int lane) {
+__device__ const uint4 knn_zero16 = {0u, 0u, 0u, 0u};
+
+// One 1-KiB piece of a database tile, global -> LDS with no register stop-over (global_load_lds_dwordx4:
+// every lane names its own 16 source bytes, the wave's 64 pieces land back to back at a wave-uniform LDS
+// address).  Piece i of wave w is half (i & 1) of tile row w * KNN_DT / NW + (i >> 1).  Rows past the end of
+// the database are read from its last row and masked out at the top-k update; lanes past the row's d elements
+// copy zeros, so the LDS columns past d are always zero and the MFMA loop needs no bounds test.
+template <int NW>
+__device__ __forceinline__ void knn_fetch_piece(const uint16_t* __restrict__ db, long t, long N, int d, char* buf, int w, int lane, int i) {
+    const int r = w * (KNN_DT / NW) + (i >> 1), h = i & 1;
+    long gr = t * KNN_DT + r;
+    gr = gr < N ? gr : N - 1;
+    const char* src = reinterpret_cast<const char*>(db + gr * (long)d) + h * 1024 + lane * 16;
+    if (h * 1024 + lane * 16 >= 2 * d) src = reinterpret_cast<const char*>(&knn_zero16);
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + r * KNN_RS + h * 1024), 16, 0, 0);
+}
+
+// min over the 16 lanes that share lane >> 4, result in all of them (DPP row rotations)
+__device__ __forceinline__ float row16_min(float v) {
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false)));
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false)));
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false)));
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false)));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+// Register top-k (k <= 16).  The kept list of query row (b, 4 lg + r) lives in hp[b][r] of the 16 lanes of
+// lane group lg -- the lanes that also receive that row's similarities from the MFMA -- and th[b][r] is its
+// minimum.  `pend` = lanes holding a similarity above their row's minimum.  Each round every lane group takes
+// its lowest pending lane, replaces the minimum of that row's list and refreshes the minimum; the four groups
+// work on four different rows at once.  Slots past k hold +INF and are never replaced.
+__device__ __forceinline__ void knn_insert(float v, unsigned long long pend, float& hp, float& th, int lane) {
+    const int lg = lane >> 4, lr = lane & 15;
+    while (pend) {  // wave-uniform
+        float cand = 0.f;
+        bool active = false;
+        unsigned long long chosen = 0;
 #pragma unroll
-    for (int i = 0; i < KNN_DT / 4; i++) {
-        const int r = w * (KNN_DT / 4) + i;
-        long gr = t * KNN_DT + r;
-        gr = gr < N ? gr : N - 1;
-        const char* src = reinterpret_cast<const char*>(db + gr * (long)d) + lane * 16;
-        char* dst = buf + r * KNN_RS;
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-            if (h * 1024 + lane * 16 < 2 * d)
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + h * 1024), (lptr_t)(dst + h * 1024), 16, 0, 0);
+        for (int g = 0; g < 4; g++) {
+            const unsigned m = (unsigned)(pend >> (16 * g)) & 0xffffu;
+            if (m) {  // uniform
+                const int src = 16 * g + __builtin_ctz(m);
+                const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+                if (lg == g) { cand = c; active = true; }
+                chosen |= 1ull << src;
+            }
+        }
+        pend &= ~chosen;
+        const bool doit = active && cand > th;
+        const unsigned long long eq = __ballot(doit && hp == th);
+        const unsigned e = (unsigned)(eq >> (16 * lg)) & 0xffffu;
+        if (doit && lr == __builtin_ctz(e | 0x10000u)) hp = cand;
+        th = row16_min(hp);
     }
 }
 
 // One database tile: 16 RPW x 32 similarities per wave on the matrix cores, then the per-row top-k update.
-// `cur` holds tile t; Sw / heap / thr are this wave's scratch rows, the kept lists and their minima.
-template <bool BF, int RPW>
-__device__ __forceinline__ void knn_tile(const char* cur, long t, long N, int k, int k4, int hs, const uint4 (&qf)[RPW][KNN_KSTEPS],
-                                         float* Sw, float* heap, float* thr, int w, int lane) {
+// `cur` holds tile t; the pieces of tile t + 1 are issued between the k-steps (an LDS-DMA issued among MFMAs
+// costs a fraction of one issued in a burst).  KREG: lists in registers (hp / th), else in LDS (Sw / heap / thr).
+template <bool BF, int RPW, int NW, bool KREG>
+__device__ __forceinline__ void knn_tile(const char* cur, char* nxt, const uint16_t* __restrict__ db, long t, long N, int d, int k,
+                                         int k4, int hs, const uint4 (&qf)[RPW][KNN_KSTEPS], float (&hp)[RPW][4],
+                                         float (&th)[RPW][4], float* Sw, float* heap, float* thr, int w, int lane) {
     constexpr int rs = KNN_RS;
+    constexpr int PIECES = 2 * KNN_DT / NW, SPP = KNN_KSTEPS / PIECES;  // pieces per wave, k-steps per piece
     const int lr = lane & 15, lg = lane >> 4;
-    const char* buf = cur;
     f32x4_t acc[RPW][2];
 #pragma unroll
     for (int b = 0; b < RPW; b++) acc[b][0] = acc[b][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const char* bp = buf + lr * rs + 16 * lg;
-    // B-fragments are read two k-steps ahead of the MFMAs that use them (one wave per SIMD: nothing
-    // else hides the LDS latency)
+    const char* bp = cur + lr * rs + 16 * lg;
+    // B-fragments are read two k-steps ahead of the MFMAs that use them
     uint4 bq[3][2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -103,6 +149,7 @@ __device__ __forceinline__ void knn_tile(const char* cur, long t, long N, int k,
             bq[(s + 2) % 3][0] = *reinterpret_cast<const uint4*>(bp + 64 * (s + 2));
             bq[(s + 2) % 3][1] = *reinterpret_cast<const uint4*>(bp + 16 * rs + 64 * (s + 2));
         }
+        if (s % SPP == 0) knn_fetch_piece<NW>(db, t + 1, N, d, nxt, w, lane, s / SPP);
         __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of this k-step's MFMAs
 #pragma unroll
         for (int b = 0; b < RPW; b++) {
@@ -112,6 +159,23 @@ __device__ __forceinline__ void knn_tile(const char* cur, long t, long N, int k,
     }
     // ---- top-k update.  acc[b][j][r] = <query 16(w RPW + b) + 4 lg + r, database row 32 t + 16 j + lr>
     const bool c0 = t * KNN_DT + lr < N, c1 = t * KNN_DT + 16 + lr < N;
+    if (KREG) {
+        bool hit = false;
+#pragma unroll
+        for (int b = 0; b < RPW; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) hit |= (c0 && acc[b][0][r] > th[b][r]) || (c1 && acc[b][1][r] > th[b][r]);
+        if (__any(hit)) {  // rare after the first tiles
+#pragma unroll
+            for (int b = 0; b < RPW; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    knn_insert(acc[b][0][r], __ballot(c0 && acc[b][0][r] > th[b][r]), hp[b][r], th[b][r], lane);
+                    knn_insert(acc[b][1][r], __ballot(c1 && acc[b][1][r] > th[b][r]), hp[b][r], th[b][r], lane);
+                }
+        }
+        return;
+    }
     // bal[b][j][r]: lanes whose value beats the current k-th best of its row (rare after the first tiles)
     unsigned long long bal[RPW][2][4];
     unsigned long long any = 0;
@@ -119,9 +183,9 @@ __device__ __forceinline__ void knn_tile(const char* cur, long t, long N, int k,
     for (int b = 0; b < RPW; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const float th = thr[(w * RPW + b) * 16 + 4 * lg + r];
-            bal[b][0][r] = __ballot(c0 && acc[b][0][r] > th);
-            bal[b][1][r] = __ballot(c1 && acc[b][1][r] > th);
+            const float tv = thr[(w * RPW + b) * 16 + 4 * lg + r];
+            bal[b][0][r] = __ballot(c0 && acc[b][0][r] > tv);
+            bal[b][1][r] = __ballot(c1 && acc[b][1][r] > tv);
             any |= bal[b][0][r] | bal[b][1][r];
         }
     if (any != 0) {  // wave-uniform
@@ -181,23 +245,24 @@ __device__ __forceinline__ void knn_tile(const char* cur, long t, long N, int k,
     }
 }
 
-// One workgroup = 4 waves x RPW blocks of 16 query rows.  LDS: two database tiles [KNN_DT][2d + 16 B],
-// per-wave similarity scratch, per-row top-k lists (unsorted, with their minimum cached in thr[]).
-template <bool BF, typename QE, int RPW>
-__global__ __launch_bounds__(256, 1) void k_knn_mean(const typename QE::storage* __restrict__ q, long n,
-                                                     const uint16_t* __restrict__ db, long N, int d, int k,
-                                                     float* __restrict__ out) {
+// One workgroup = NW waves x RPW blocks of 16 query rows, whose d-long rows stay in registers as MFMA
+// A-fragments for the whole sweep over the database.  LDS: two database tiles [KNN_DT][2064 B] and, when k > 16,
+// per-wave similarity scratch and per-row kept lists (unsorted, their minimum cached in thr[]).
+template <bool BF, typename QE, int RPW, int NW, bool KREG>
+__global__ __launch_bounds__(64 * NW, 1) void k_knn_mean(const typename QE::storage* __restrict__ q, long n,
+                                                         const uint16_t* __restrict__ db, long N, int d, int k,
+                                                         float* __restrict__ out) {
     // Two tile buffers as two LDS objects: the compiler then knows that the ds_reads of one never touch the
     // tile an LDS-DMA is still filling, and does not drain the DMA (s_waitcnt vmcnt(0)) in front of them.
     __shared__ __attribute__((aligned(16))) char tile0[KNN_DT * KNN_RS];
     __shared__ __attribute__((aligned(16))) char tile1[KNN_DT * KNN_RS];
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int QT = 64 * RPW;
+    constexpr int QT = 16 * RPW * NW, NT = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
-    float* S = reinterpret_cast<float*>(smem);                   // [4][16 * RPW][KNN_SPAD]
+    float* S = reinterpret_cast<float*>(smem);                   // [NW][16 * RPW][KNN_SPAD]
     const int k4 = (k + 3) & ~3, hs = k4 + 4;                    // list stride: 16-byte groups + one group of padding
-    float* heap = S + 4 * 16 * RPW * KNN_SPAD;                   // [QT][hs]: k kept values, +INF in the slots past k
+    float* heap = S + NW * 16 * RPW * KNN_SPAD;                  // [QT][hs]: k kept values, +INF in the slots past k
     float* thr = heap + QT * hs;                                 // [QT]
 
     // ---- query rows -> unit norm (faiss.normalize_L2, score_align.py:133-134) -> MFMA A-fragments
@@ -236,29 +301,46 @@ __global__ __launch_bounds__(256, 1) void k_knn_mean(const typename QE::storage*
             qf[b][s] = v;
         }
     }
-    for (int i = tid; i < KNN_DT * KNN_RS / 16; i += 256) {
-        reinterpret_cast<uint4*>(tile0)[i] = make_uint4(0, 0, 0, 0);
-        reinterpret_cast<uint4*>(tile1)[i] = make_uint4(0, 0, 0, 0);
+    float hp[RPW][4], th[RPW][4];
+#pragma unroll
+    for (int b = 0; b < RPW; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            hp[b][r] = lr < k ? -INFINITY : INFINITY;
+            th[b][r] = -INFINITY;
+        }
+    if (!KREG) {
+        for (int i = tid; i < QT * hs; i += NT) heap[i] = (i % hs) < k ? -INFINITY : INFINITY;
+        for (int i = tid; i < QT; i += NT) thr[i] = -INFINITY;
     }
-    for (int i = tid; i < QT * hs; i += 256) heap[i] = (i % hs) < k ? -INFINITY : INFINITY;
-    for (int i = tid; i < QT; i += 256) thr[i] = -INFINITY;
 
     const long ntiles = (N + KNN_DT - 1) / KNN_DT;
-    __syncthreads();  // (tiles cleared)
-    if (ntiles > 0) knn_fetch(db, 0, N, d, tile0, w, lane);
+    constexpr int PIECES = 2 * KNN_DT / NW;
+    if (ntiles > 0) {
+#pragma unroll
+        for (int i = 0; i < PIECES; i++) knn_fetch_piece<NW>(db, 0, N, d, tile0, w, lane, i);
+    }
     __syncthreads();
 
     float* Sw = S + w * 16 * RPW * KNN_SPAD;
+    // (the last tile's step fetches "tile ntiles": clamped to the last row, never computed)
     for (long t = 0; t < ntiles; t += 2) {
-        if (t + 1 < ntiles) knn_fetch(db, t + 1, N, d, tile1, w, lane);
-        knn_tile<BF, RPW>(tile0, t, N, k, k4, hs, qf, Sw, heap, thr, w, lane);
+        knn_tile<BF, RPW, NW, KREG>(tile0, tile1, db, t, N, d, k, k4, hs, qf, hp, th, Sw, heap, thr, w, lane);
         __syncthreads();
         if (t + 1 >= ntiles) break;
-        if (t + 2 < ntiles) knn_fetch(db, t + 2, N, d, tile0, w, lane);
-        knn_tile<BF, RPW>(tile1, t + 1, N, k, k4, hs, qf, Sw, heap, thr, w, lane);
+        knn_tile<BF, RPW, NW, KREG>(tile1, tile0, db, t + 1, N, d, k, k4, hs, qf, hp, th, Sw, heap, thr, w, lane);
         __syncthreads();
     }
-    if (lane < 16 * RPW) {
+    if (KREG) {
+#pragma unroll
+        for (int b = 0; b < RPW; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float sum = row16_sum(lr < k ? hp[b][r] : 0.f);
+                const long qrow = (long)blockIdx.x * QT + (w * RPW + b) * 16 + 4 * lg + r;
+                if (lr == 0 && qrow < n) out[qrow] = sum / (float)k;
+            }
+    } else if (lane < 16 * RPW) {
         const int qi = w * RPW * 16 + lane;
         const long qrow = (long)blockIdx.x * QT + qi;
         if (qrow < n) {
@@ -334,30 +416,42 @@ __global__ __launch_bounds__(256) void k_unit_rows(const typename QE::storage* _
 }
 
 // ------------------------------------------------------------------------------------ launchers
-static size_t knn_smem(int d, int k, int rpw) {
-    return (size_t)4 * 16 * rpw * KNN_SPAD * 4 + (size_t)64 * rpw * (((k + 3) & ~3) + 5) * 4;
+static size_t knn_smem(int k, int rpw, int nw) {
+    return (size_t)nw * 16 * rpw * KNN_SPAD * 4 + (size_t)16 * nw * rpw * (((k + 3) & ~3) + 5) * 4;
 }
 
-template <bool BF, typename QE, int RPW>
-static int launch_knn(svx_ctx* ctx, const void* q, long n, const void* db, long N, int d, int k, float* out) {
-    const size_t smem = knn_smem(d, k, RPW);
+template <bool BF, typename QE, int RPW, int NW, bool KREG>
+static int launch_knn_k(svx_ctx* ctx, const void* q, long n, const void* db, long N, int d, int k, float* out) {
+    const size_t smem = KREG ? 0 : knn_smem(k, RPW, NW);
     static size_t attr_set = 0;
     if (smem > attr_set) {
-        SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_knn_mean<BF, QE, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_knn_mean<BF, QE, RPW, NW, KREG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = smem;
     }
-    const long nblk = (n + 64 * RPW - 1) / (64 * RPW);
-    k_knn_mean<BF, QE, RPW><<<dim3((unsigned)nblk), dim3(256), smem, ctx->stream>>>(
+    const long qt = 16 * RPW * NW;
+    k_knn_mean<BF, QE, RPW, NW, KREG><<<dim3((unsigned)((n + qt - 1) / qt)), dim3(64 * NW), smem, ctx->stream>>>(
         reinterpret_cast<const typename QE::storage*>(q), n, reinterpret_cast<const uint16_t*>(db), N, d, k, out);
     SVX_LAUNCH_CHECK(ctx, "k_knn_mean");
     return SVX_OK;
 }
 
+template <bool BF, typename QE, int RPW, int NW>
+static int launch_knn(svx_ctx* ctx, const void* q, long n, const void* db, long N, int d, int k, float* out) {
+    if (k <= 16) return launch_knn_k<BF, QE, RPW, NW, true>(ctx, q, n, db, N, d, k, out);
+    return launch_knn_k<BF, QE, RPW, NW, false>(ctx, q, n, db, N, d, k, out);
+}
+
+// Shapes: (RPW, NW) = (1, 4): 64 queries per workgroup, for small query sets; (2, 4): 128 queries, half the LDS
+// fragment reads per MFMA, one wave per SIMD (the default for large query sets: 870 TFLOP/s at 131072^2 x 1024,
+// k = 16); (1, 8): 128 queries as two waves per SIMD (854 TFLOP/s).
 template <bool BF, typename QE>
 static int launch_knn_rpw(svx_ctx* ctx, const void* q, long n, const void* db, long N, int d, int k, float* out) {
-    // two 16-row blocks per wave halve the LDS reads per MFMA; worth it once the grid still fills the chip
-    if (n >= 128 * 256 && knn_smem(d, k, 2) + 2 * KNN_DT * KNN_RS <= 160 * 1024) return launch_knn<BF, QE, 2>(ctx, q, n, db, N, d, k, out);
-    return launch_knn<BF, QE, 1>(ctx, q, n, db, N, d, k, out);
+    const char* force = getenv("SVX_KNN_SHAPE");  // tuning override: "14", "18", "24"
+    const int shape = force ? atoi(force) : (n >= 128 * 128 ? 24 : 14);
+    const size_t tiles = (size_t)2 * KNN_DT * KNN_RS;
+    if (shape == 24 && knn_smem(k, 2, 4) + tiles <= 160 * 1024) return launch_knn<BF, QE, 2, 4>(ctx, q, n, db, N, d, k, out);
+    if (shape == 18 && knn_smem(k, 1, 8) + tiles <= 160 * 1024) return launch_knn<BF, QE, 1, 8>(ctx, q, n, db, N, d, k, out);
+    return launch_knn<BF, QE, 1, 4>(ctx, q, n, db, N, d, k, out);
 }
 
 #define NEED(ctx, cond, ...) \
