@@ -160,11 +160,32 @@ def gen_margin(ref_root):
     print("margin_example.npz:", os.path.getsize(os.path.join(HERE, "margin_example.npz")) // 1024, "KiB")
 
 
+def gen_post(ref_root):
+    """Data files of the reference's shipped example for the manifest steps after margin scoring (copied as
+    they are): segment files, the margin-scored alignment file, and the three manifests made from it."""
+    import shutil
+    ex = os.path.join(ref_root, "example", "voxpopuli")
+    stem = "20180313-0900-PLENARY-15"
+    od = os.path.join(HERE, "example_post")
+    os.makedirs(od, exist_ok=True)
+    for src, dst in ((f"segments/en/{stem}_en.txt", "segments_en.txt"), (f"segments/de/{stem}_de.txt", "segments_de.txt"),
+                     ("metadata.tsv", "metadata.tsv"),
+                     (f"align_0.7_clean_cat3_min1s_margin/en-de/{stem}_en-{stem}_de.txt", "margin.txt"),
+                     ("align_0.7_clean_cat3_min1s_tsvs/en-de/align.tsv.gz", "align.tsv.gz"),
+                     ("align_0.7_clean_cat3_min1s_tsvs/en-de/align.rm_overlap.tsv.gz", "align.rm_overlap.tsv.gz"),
+                     ("align_0.7_clean_cat3_min1s_tsvs/en-de/align.rm_overlap.sort.tsv.gz", "align.rm_overlap.sort.tsv.gz")):
+        shutil.copyfile(os.path.join(ex, src), os.path.join(od, dst))
+        os.chmod(os.path.join(od, dst), 0o644)
+    print("example_post:", sum(os.path.getsize(os.path.join(od, f)) for f in os.listdir(od)) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["ops", "pipeline", "example", "margin"]
+    what = sys.argv[1:] or ["ops", "pipeline", "example", "margin", "post"]
+    if "post" in what:
+        gen_post(ref_loader.REF_ROOT)
     if "margin" in what:
         gen_margin(ref_loader.REF_ROOT)
-    if set(what) - {"margin"}:
+    if set(what) - {"margin", "post"}:
         ref = ref_loader.load()
         if "ops" in what:
             gen_ops(ref)

@@ -276,3 +276,47 @@ def test_postfilters_regenerate_shipped_example(tmp_path):
     filter_by_dur.main([meta, str(tmp_path / "d"), "--align_dir", os.path.join(ex, "align_0.7_clean_cat3"),
                         "--seg_dir", os.path.join(ex, "segments")] + common)
     assert open(tmp_path / "d" / name).read() == open(os.path.join(ex, "align_0.7_clean_cat3_min1s", name)).read()
+
+
+# ---- manifest steps after margin scoring (prep_tsv.py, sort_tsv.py) on the reference's shipped example -------------
+POST = os.path.join(os.path.dirname(__file__), "golden", "example_post")
+
+
+def _gz_lines(path):
+    import gzip
+    with gzip.open(path, "rt") as f:
+        return f.read().splitlines()
+
+
+def test_prep_tsv_reproduces_shipped_manifest(tmp_path):
+    """margin-scored alignments + segment files -> align.tsv.gz, line for line as shipped."""
+    import shutil
+    from svx.postprocess import prep_tsv
+    stem = "20180313-0900-PLENARY-15"
+    (tmp_path / "margin" / "en-de").mkdir(parents=True)
+    (tmp_path / "seg" / "en").mkdir(parents=True)
+    (tmp_path / "seg" / "de").mkdir(parents=True)
+    shutil.copy(os.path.join(POST, "margin.txt"), tmp_path / "margin" / "en-de" / f"{stem}_en-{stem}_de.txt")
+    shutil.copy(os.path.join(POST, "segments_en.txt"), tmp_path / "seg" / "en" / f"{stem}_en.txt")
+    shutil.copy(os.path.join(POST, "segments_de.txt"), tmp_path / "seg" / "de" / f"{stem}_de.txt")
+    meta = tmp_path / "metadata.tsv"
+    meta.write_text(open(os.path.join(POST, "metadata.tsv")).read() + "a/none_en.ogg\ta/none_de.ogg\n")
+    args = [str(meta), str(tmp_path / "tsv"), "--src_lang", "en", "--tgt_lang", "de", "--align_dir", str(tmp_path / "margin"),
+            "--seg_dir", str(tmp_path / "seg")]
+    prep_tsv.main(args)
+    got = _gz_lines(tmp_path / "tsv" / "en-de" / "align.tsv.gz")
+    assert got == _gz_lines(os.path.join(POST, "align.tsv.gz")) and len(got) == 347
+    with pytest.raises(AssertionError, match="Will not overwrite"):
+        prep_tsv.main(args)
+
+
+def test_sort_tsv_reproduces_shipped_manifest(tmp_path):
+    from svx.postprocess import sort_tsv
+    out = tmp_path / "o" / "sorted.tsv.gz"
+    sort_tsv.main(["--in_tsv", os.path.join(POST, "align.rm_overlap.tsv.gz"), "--out_tsv", str(out)])
+    got = _gz_lines(out)
+    assert got == _gz_lines(os.path.join(POST, "align.rm_overlap.sort.tsv.gz")) and len(got) == 300
+    scores = [float(l.split("\t")[0]) for l in got]
+    assert scores == sorted(scores, reverse=True)
+    with pytest.raises(AssertionError, match="exists"):
+        sort_tsv.main(["--in_tsv", os.path.join(POST, "align.rm_overlap.tsv.gz"), "--out_tsv", str(out)])
