@@ -168,6 +168,25 @@ def test_sakoe_chiba_band_vs_oracle(orc):
     assert np.abs(sc_g - sc_o).max() < SCORE_TOL
 
 
+def test_sakoe_chiba_full_size_equals_coarse_to_fine():
+    """BASELINE configs[3] at full size -- N = M = 32768, d = 1024, band 2048 around the straight diagonal
+    (no CPU implementation finishes this in test time: 2.7e9 cost cells).  Size-independent property instead:
+    both search modes evaluate the same recurrence, and for a pair whose true path stays inside both search
+    regions the banded optimum and the coarse-to-fine optimum are the same alignment ("Modes")."""
+    from svx.vecalign import dp_utils
+    N = M = 32768
+    v0, v1 = make_pair(N, M, 4, 1024, 5)
+    types = alignment_types(5)
+    np.random.seed(1)
+    st = dp_utils.vecalign(v0, v1, types, 0.2, 7, 300, 20000, 100)
+    np.random.seed(1)
+    al_c, sc_c = dp_utils.align_band(v0, v1, types, 0.2, 1024, 20000, 100)
+    al_a, sc_a = st[0]['final_alignments'], st[0]['alignment_scores']
+    assert [x for al in al_c for x in al[0]] == list(range(N)) and [y for al in al_c for y in al[1]] == list(range(M))
+    assert al_c == al_a
+    assert np.abs(np.asarray(sc_c) - np.asarray(sc_a)).max() < SCORE_TOL
+
+
 def test_ragged_batch_up_to_8192(orc):
     """BASELINE configs[2] shape: one batch of pairs with N, M drawn from [512, 8192]; every pair is
     checked for full monotone coverage, the largest one against the oracle."""
