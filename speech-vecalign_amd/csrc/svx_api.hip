@@ -43,7 +43,7 @@ struct svx_ctx_ext : svx_ctx {
     // kernels (DP, traceback) of one sub-batch overlap the streaming kernels of the other
     int n_streams;
     hipStream_t aux[3];
-    hipEvent_t fork_ev, join_ev[3];
+    hipEvent_t fork_ev, join_ev[3], stag_ev[3];
     bool aux_ready;
 };
 
@@ -104,7 +104,7 @@ int svx_destroy(svx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (X(ctx)->aux_ready) {
-        for (int i = 0; i < 3; i++) { (void)hipStreamDestroy(X(ctx)->aux[i]); (void)hipEventDestroy(X(ctx)->join_ev[i]); }
+        for (int i = 0; i < 3; i++) { (void)hipStreamDestroy(X(ctx)->aux[i]); (void)hipEventDestroy(X(ctx)->join_ev[i]); (void)hipEventDestroy(X(ctx)->stag_ev[i]); }
         (void)hipEventDestroy(X(ctx)->fork_ev);
     }
     delete X(ctx);
@@ -555,7 +555,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
     for (int i = 0; i < S_COUNT; i++) { cx->ms[i] = 0.0; cx->launches[i] = 0; }
     for (auto& r : cx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     cx->recs.clear();
-    auto run_stages = [&](SvxPairDev* dp, int np) -> int {
+    auto run_stages = [&](SvxPairDev* dp, int np, hipEvent_t streamed_ev) -> int {
         int rc2;
         for (int l = 0; l <= maxL; l++) {
             // pyramid: the streaming pass of level l (S_PYR0 / S_PYRN) and its small helpers
@@ -578,6 +578,8 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             StageScope sc(ctx, S_KNOB_SCORES0);
             if ((rc2 = svxl_knob_scores(ctx, dp, np, maxL, max_kn, max_n0, dtype, d, 2))) return rc2;
         }
+        // (the next sub-batch starts its streaming passes here: they overlap this one's serial DP stages)
+        if (streamed_ev) SVX_HIP(ctx, hipEventRecord(streamed_ev, ctx->stream));
         {
             StageScope sc(ctx, S_KNOB);
             if ((rc2 = svxl_del_penalty_batch(ctx, dp, np, maxL + 1, prm->del_percentile_frac))) return rc2;
@@ -630,12 +632,13 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         }
         const int S = cx->n_streams < n_pairs ? cx->n_streams : n_pairs;
         if (S <= 1) {
-            if ((rc = run_stages(dpairs, n_pairs))) return rc;
+            if ((rc = run_stages(dpairs, n_pairs, nullptr))) return rc;
         } else {
             if (!cx->aux_ready) {
                 for (int i = 0; i < 3; i++) {
                     SVX_HIP(ctx, hipStreamCreateWithFlags(&cx->aux[i], hipStreamNonBlocking));
                     SVX_HIP(ctx, hipEventCreateWithFlags(&cx->join_ev[i], hipEventDisableTiming));
+                    SVX_HIP(ctx, hipEventCreateWithFlags(&cx->stag_ev[i], hipEventDisableTiming));
                 }
                 SVX_HIP(ctx, hipEventCreateWithFlags(&cx->fork_ev, hipEventDisableTiming));
                 cx->aux_ready = true;
@@ -644,9 +647,11 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             for (int s2 = 0; s2 < S; s2++) {
                 const int lo = (int)((long long)n_pairs * s2 / S), hi = (int)((long long)n_pairs * (s2 + 1) / S);
                 hipStream_t ss = s2 == 0 ? st : cx->aux[s2 - 1];
+                // sub-batch s2 waits until sub-batch s2-1 has finished its streaming front (pyramid + sampled scores)
                 if (s2 > 0) SVX_HIP(ctx, hipStreamWaitEvent(ss, cx->fork_ev, 0));
+                if (s2 > 0) SVX_HIP(ctx, hipStreamWaitEvent(ss, cx->stag_ev[s2 - 1], 0));
                 ctx->stream = ss;
-                rc = run_stages(dpairs + lo, hi - lo);
+                rc = run_stages(dpairs + lo, hi - lo, s2 + 1 < S ? cx->stag_ev[s2] : nullptr);
                 ctx->stream = st;
                 if (rc) return rc;
                 if (s2 > 0) {

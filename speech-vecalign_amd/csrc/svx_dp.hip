@@ -201,67 +201,111 @@ __device__ void sparse_dp_block(const SparseDpArgs& g, const SvxTypes& ty, doubl
     }
 }
 
-// Fast kernel for narrow bands (B <= 64): wave 0 sweeps the diagonals touching only LDS -- the
-// csum ring, a ring of b_offset_out and a double-buffered chunk of CH diagonals of costs -- while
-// waves 1-3 stage the next chunk from HBM, so no global load sits on the serial chain.
+// Fast kernel for narrow bands (B <= 64).  Waves 1-3 turn the next chunk of CH node diagonals into three LDS
+// tables -- the cost of every (diagonal, type, cell), the csum-ring slot of its predecessor node (or a slot that
+// holds +inf when the move is not allowed) and one word per node with its border case and the lanes of its two
+// deletion predecessors -- so that wave 0, which carries the serial chain, does no index arithmetic at all: per
+// type move two table reads, one ring read, one add and one compare.
 constexpr int DPF_THREADS = 256;
 
+__host__ __device__ inline size_t dpf_align16(size_t v) { return (v + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t dpf_chunk_bytes(int T, int B, int CH) {
+    const size_t cells = (size_t)CH * (T > 0 ? T : 1) * B;
+    return dpf_align16(cells * sizeof(float)) + dpf_align16(cells * sizeof(unsigned short)) + dpf_align16((size_t)CH * B * sizeof(unsigned));
+}
 __host__ __device__ inline size_t dpf_smem_bytes(int T, int B, int RD, int CH) {
-    return (size_t)RD * B * sizeof(double)                      // csum ring
-           + (size_t)(SVX_MAX_TYPES + 2) * sizeof(int)          // packed transitions
-           + 2 * (size_t)CH * sizeof(int)                       // b_offset_out of the chunk
-           + 2 * (size_t)CH * (T + 2) * sizeof(int)             // lane shift per (diagonal, transition)
-           + 2 * (size_t)CH * (T > 0 ? T : 1) * B * sizeof(float);  // costs
+    return dpf_align16(((size_t)RD * B + 1) * sizeof(double))   // csum ring + the +inf slot
+           + dpf_align16((size_t)(SVX_MAX_TYPES + 2) * sizeof(int))  // packed transitions
+           + 2 * dpf_chunk_bytes(T, B, CH) + 2 * (dpf_align16((size_t)CH * B * sizeof(double)) + dpf_align16((size_t)CH * B * sizeof(int)))
+           + dpf_align16((size_t)4 * (CH + RD) * sizeof(int));   // per-wave band-offset tables of the staging code
 }
 
-// Stage chunk c (node diagonals a0 .. a0+CH-1) into buffer c&1: b_offset_out, the lane shift of every
-// transition and the cost rows a-2.  Everything is derived from global memory (b_offset_in is tiny
-// and cached), so the staging waves need no hand-off between themselves.
-__device__ __forceinline__ void dpf_stage(const SparseDpArgs& g, const int* tpk, int T, int CH, int c, int* bo_buf, int* sh_buf,
-                                          float* cbuf, int tsub, int nsub) {
-    const int A = g.A, B = g.B, Aout = A + 2, NTt = T + 2;
+// node word: kind (2 bits: 0 general, 1 border x == 0, 2 border y == 0, 3 outside) | lane of the (0,1) predecessor
+// (7 bits, 127 = none) << 2 | lane of the (1,0) predecessor << 9.  (A border node of diagonal a costs pen * a.)
+__device__ __forceinline__ int dpf_boff_out(const SparseDpArgs& g, int a) { return a < 2 ? g.boff_in[0] : g.boff_in[a - 2] + 1; }
+
+// Stage chunk c (node diagonals a0 .. a0+CH-1) into buffer c & 1.  Every staging wave first copies the band
+// offsets of diagonals a0-RD .. a0+CH-1 into its own small LDS table (one global round trip, no hand-off between
+// waves); the chunk's costs are one contiguous run in the pipeline's [A][T][B] layout and move as 16-byte pieces.
+// wboff: [4 waves][CH + RD] ints.
+__device__ __forceinline__ void dpf_stage(const SparseDpArgs& g, const int* tpk, int T, int RD, int CH, int c, char* bufs, int* wboff,
+                                          int tsub, int nsub) {
+    const int A = g.A, B = g.B, Aout = A + 2;
     const int a0 = c * CH;
-    int* bo = bo_buf + (size_t)(c & 1) * CH;
-    int* sh = sh_buf + (size_t)(c & 1) * CH * NTt;
-    for (int i = tsub; i < CH; i += nsub) {
-        const int a = a0 + i;
-        bo[i] = (a < Aout) ? (a < 2 ? g.boff_in[0] : g.boff_in[a - 2] + 1) : 0;
-    }
-    for (int idx = tsub; idx < CH * NTt; idx += nsub) {
-        const int i = idx / NTt, t = idx - i * NTt;
-        const int a = a0 + i;
-        const int pk = tpk[t];
-        const int yo = (pk >> 8) & 255, st = pk >> 16;
-        int v = 1 << 20;  // no predecessor diagonal: pushes the lane index out of the band
-        if (a < Aout && a - st >= 0) {
-            const int boa = a < 2 ? g.boff_in[0] : g.boff_in[a - 2] + 1;
-            const int ap = a - st;
-            const int bop = ap < 2 ? g.boff_in[0] : g.boff_in[ap - 2] + 1;
-            v = boa - yo - bop;  // predecessor cell = lane + v on diagonal a - st
-        }
-        sh[idx] = v;
-    }
+    const int Tn = T > 0 ? T : 1;
+    char* base = bufs + (size_t)(c & 1) * dpf_chunk_bytes(T, B, CH);
+    float* cost = reinterpret_cast<float*>(base);
+    unsigned short* idx = reinterpret_cast<unsigned short*>(base + dpf_align16((size_t)CH * Tn * B * sizeof(float)));
+    unsigned* node = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(idx) + dpf_align16((size_t)CH * Tn * B * sizeof(unsigned short)));
+    const int dummy = RD * B;
     const int TB = T * B;
-    const int total = CH * TB;
-    float* dst = cbuf + (size_t)(c & 1) * total;
-    if (g.atb) {
-        // [A][T][B]: the chunk is one contiguous run of cost rows a0-2 .. a0-2+CH
-        const long long first = (long long)(a0 - 2) * TB;
-        const long long limit = (long long)A * TB;
-        for (int idx = tsub; idx < total; idx += nsub) {
-            const long long o = first + idx;
-            dst[idx] = (o >= 0 && o < limit) ? g.costs[o] : 0.f;
+    const int lim = Aout - 1;
+    // ---- this wave's table of b_offset_out[a0 - RD + k], k < CH + RD
+    int* wb = wboff + ((threadIdx.x >> 6) & 3) * (CH + RD);
+    for (int k = threadIdx.x & 63; k < CH + RD; k += 64) {
+        int a = a0 - RD + k;
+        a = a < 0 ? 0 : (a > lim ? lim : a);
+        const int raw = g.boff_in[a < 2 ? 0 : a - 2];
+        wb[k] = a < 2 ? raw : raw + 1;
+    }
+    // ---- costs
+    const bool block_copy = g.atb && (TB % 4 == 0) && ((reinterpret_cast<size_t>(g.costs) & 15) == 0);
+    if (block_copy) {
+        // cost row of node diagonal a is a - 2: rows a0-2 .. a0+CH-3, rows outside [0, A) are zero
+        const long long first = (long long)(a0 - 2) * TB, limit = (long long)A * TB;
+        for (int q = tsub; q < CH * TB / 4; q += nsub) {
+            const long long o = first + 4ll * q;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (o >= 0 && o + 4 <= limit) v = *reinterpret_cast<const uint4*>(g.costs + o);
+            reinterpret_cast<uint4*>(cost)[q] = v;
         }
-    } else {
-        for (int idx = tsub; idx < total; idx += nsub) {
-            const int i = idx / TB, rem = idx - i * TB;
-            const int ac = a0 + i - 2;  // cost row of node diagonal a0 + i
-            float v = 0.f;
-            if (ac >= 0 && ac < A) {
-                const int t = rem / B, b = rem - t * B;
-                v = g.costs[cost_index(g, T, t, ac, b)];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- index tables: one thread per column -- a (type, cell) pair or, past those, a node cell -- walking down
+    // the chunk's diagonals; with fewer columns than staging threads the diagonals are split over thread groups
+    const int ncols = TB + B;
+    const int ngroups = nsub / ncols > 0 ? nsub / ncols : 1;
+    for (int cg = tsub; cg < ncols * ngroups; cg += nsub) {
+        const int col = cg % ncols, grp = cg / ncols;
+        const bool is_node = col >= TB;
+        const int t = is_node ? 0 : col / B;
+        const int b = is_node ? col - TB : col - t * B;
+        const int pk = (!is_node && T > 0) ? tpk[t] : (1 << 16);
+        const int xo = pk & 255, yo = (pk >> 8) & 255, st = is_node ? 1 : pk >> 16;
+        int sl = (a0 + grp - st) % RD;  // ring slot of diagonal a - st
+        sl = sl < 0 ? sl + RD : sl;
+        const int step = ngroups % RD;
+#pragma unroll 4
+        for (int i = grp; i < CH; i += ngroups) {
+            const int a = a0 + i;
+            const bool in = a <= lim;
+            const int ac = a - 2, ap = a - st;
+            const int boa = wb[RD + i];        // b_offset_out[a]
+            const int bop = wb[RD + i - st];   // b_offset_out[a - st]
+            const int yy = b + boa, xx = a - yy;
+            const bool general = in && 1 <= xx && xx <= g.xs && 1 <= yy && yy <= g.ys && ac < A;
+            if (is_node) {
+                const int b01 = b + boa - 1 - bop, b10 = b + boa - bop;
+                unsigned w = 3u | (127u << 2) | (127u << 9);
+                if (in && xx == 0 && 0 <= yy && yy <= g.ys) w = 1u | (127u << 2) | (127u << 9);
+                else if (in && yy == 0 && 0 <= xx && xx <= g.xs) w = 2u | (127u << 2) | (127u << 9);
+                else if (general)
+                    w = ((unsigned)((0 <= b01 && b01 < B) ? b01 : 127) << 2) | ((unsigned)((0 <= b10 && b10 < B) ? b10 : 127) << 9);
+                node[i * B + b] = w;
+            } else {
+                if (!block_copy) {
+                    const int acc = ac < 0 ? 0 : (ac >= A ? A - 1 : ac);
+                    const float cv = g.costs[cost_index(g, T, t, acc, b)];
+                    cost[i * TB + col] = (in && ac >= 0 && ac < A) ? cv : 0.f;
+                }
+                const int bpv = b + boa - yo - bop;
+                const bool ok = general && ap >= 0 && xo <= xx && yo <= yy && 0 <= bpv && bpv < B;
+                idx[i * TB + col] = (unsigned short)(ok ? sl * B + bpv : dummy);
             }
-            dst[idx] = v;
+            sl += step;
+            sl = sl >= RD ? sl - RD : sl;
         }
     }
 }
@@ -286,192 +330,176 @@ __device__ __forceinline__ double xchg32_f64(double v, int lane) {
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
-// G lane groups of LB = 64/G lanes share one diagonal: lane = grp*LB + b, group grp relaxes the
-// transitions t = grp, grp+G, ...; the per-group winners are merged by (total, t) so that the
-// reference's "first strictly smaller candidate wins" order is preserved exactly.
-template <int TPLT>
+// Results of a chunk wait in LDS (csum + winning move per node) and are written to the node arrays by the staging
+// waves while wave 0 is already sweeping the next chunk.
+__host__ __device__ inline size_t dpf_out_bytes(int B, int CH) { return dpf_align16((size_t)CH * B * sizeof(double)) + dpf_align16((size_t)CH * B * sizeof(int)); }
+
+__device__ __forceinline__ void dpf_flush(const SparseDpArgs& g, const char* obuf, int B, int CH, int a0, int a_end, int tsub, int nsub) {
+    const double* ob = reinterpret_cast<const double*>(obuf);
+    const int* ok = reinterpret_cast<const int*>(obuf + dpf_align16((size_t)CH * B * sizeof(double)));
+    const int n = (a_end - a0) * B;
+    for (int e = tsub; e < n; e += nsub) {
+        const int key = ok[e];
+        const int bx = key == 0x7fffffff ? -42 : (key & 255), by = key == 0x7fffffff ? -42 : ((key >> 8) & 255);
+        store_node(g, (size_t)a0 * B + e, ob[e], bx, by);
+    }
+}
+
+// G lane groups of LB = 64/G lanes share one diagonal: lane = grp*LB + b.  Group grp relaxes the alignment types
+// t = grp, grp+G, ...; the per-group winners are merged by (total, t) so that the reference's "first strictly
+// smaller candidate wins" order is preserved exactly.  Alignment types move at least two diagonals back, so their
+// part of diagonal a+1 only needs diagonals <= a-1 and is worked out while diagonal a is being finished; what
+// stays on the serial chain is the pair of deletions, the only moves that look at diagonal a-1: that diagonal is
+// kept in a register (`cur`, every lane group holds a copy) and its two neighbours come through ds_bpermute.
+// The sweep is a single wave issuing one instruction every few cycles, so its cost is its instruction count:
+// no index arithmetic (staged tables), no branches, no global stores (dpf_flush).
+template <int TPLT, int G>
 __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH, char* smem) {
     constexpr int DPF_TPL = TPLT > 0 ? TPLT : 1;
+    constexpr bool unrolled = TPLT > 0;  // the launcher picks TPLT = ceil(T / G) when it is <= 6
+    constexpr int LB = 64 / G;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int A = g.A, B = g.B, Aout = A + 2, T = ty.n, NTt = ty.n + 2, RD = ty.maxstep + 1;
-    const int G = B <= 16 ? 4 : (B <= 32 ? 2 : 1);
-    const int LB = 64 / G;
     const int b = lane & (LB - 1), grp = lane / LB;
-    constexpr bool pipelined = TPLT > 0;  // the launcher picks TPLT = ceil((T+2)/G) when it is <= 6
+    const int Tn = T > 0 ? T : 1;
     double* ring = reinterpret_cast<double*>(smem);
-    int* tpk = reinterpret_cast<int*>(ring + (size_t)RD * B);
-    int* bo_buf = tpk + (SVX_MAX_TYPES + 2);
-    int* sh_buf = bo_buf + 2 * CH;
-    float* cbuf = reinterpret_cast<float*>(sh_buf + 2 * (size_t)CH * NTt);
-    const int TB = T * B;
+    int* tpk = reinterpret_cast<int*>(smem + dpf_align16(((size_t)RD * B + 1) * sizeof(double)));
+    char* bufs = reinterpret_cast<char*>(tpk) + dpf_align16((size_t)(SVX_MAX_TYPES + 2) * sizeof(int));
+    const size_t chunk_bytes = dpf_chunk_bytes(T, B, CH);
+    char* obufs = bufs + 2 * chunk_bytes;
+    const size_t out_bytes = dpf_out_bytes(B, CH);
+    int* wboff = reinterpret_cast<int*>(obufs + 2 * out_bytes);
+    const size_t idx_off = dpf_align16((size_t)CH * Tn * B * sizeof(float));
+    const size_t node_off = idx_off + dpf_align16((size_t)CH * Tn * B * sizeof(unsigned short));
+    const double inf = __builtin_inf();
     for (int t = tid; t < NTt; t += DPF_THREADS) tpk[t] = (int)ty.x[t] | ((int)ty.y[t] << 8) | (((int)ty.x[t] + (int)ty.y[t]) << 16);
     for (int a = tid; a < Aout; a += DPF_THREADS) g.boff_out[a] = a < 2 ? g.boff_in[0] : g.boff_in[a - 2] + 1;
+    for (int e = tid; e <= RD * B; e += DPF_THREADS) ring[e] = inf;
     __syncthreads();
-    dpf_stage(g, tpk, T, CH, 0, bo_buf, sh_buf, cbuf, tid, DPF_THREADS);
+    dpf_stage(g, tpk, T, RD, CH, 0, bufs, wboff, tid, DPF_THREADS);
     __syncthreads();
     const int nchunks = (Aout + CH - 1) / CH;
-    const double inf = __builtin_inf();
     const double pen = g.pen;
-    int slot = 0;  // a % RD, maintained incrementally (wave 0 only)
+    const int key01 = 1 << 8, key10 = 1;             // (xo, yo) of the two deletions; they come last in the order
+    const int gbase = lane & ~(LB - 1);
+    const int bb = b < B ? b : 0;  // idle lanes of a group shadow cell 0 (they never store)
+    // this lane's alignment types: offsets into one diagonal's [T][B] tables and merge keys
+    int toff[DPF_TPL], tkey[DPF_TPL];
+    bool tval[DPF_TPL];
+#pragma unroll
+    for (int j = 0; j < DPF_TPL; j++) {
+        const int t = grp + G * j;
+        const int tc = t < T ? t : Tn - 1;
+        tval[j] = t < T;
+        toff[j] = tc * B + bb;
+        tkey[j] = (t << 16) | (tpk[tc < NTt ? tc : 0] & 0xffff);  // ordered by t; carries (xo, yo) through the merge
+    }
+    int slot = 0;       // a % RD, maintained incrementally (wave 0 only)
+    double cur = inf;   // csum of this lane's cell on the previous diagonal
     for (int c = 0; c < nchunks; c++) {
         const int a0 = c * CH;
         if (wave >= 1) {
-            if (c + 1 < nchunks) dpf_stage(g, tpk, T, CH, c + 1, bo_buf, sh_buf, cbuf, tid - 64, DPF_THREADS - 64);
+            if (c + 1 < nchunks) dpf_stage(g, tpk, T, RD, CH, c + 1, bufs, wboff, tid - 64, DPF_THREADS - 64);
+            if (c > 0) dpf_flush(g, obufs + (size_t)((c - 1) & 1) * out_bytes, B, CH, a0 - CH, a0, tid - 64, DPF_THREADS - 64);
         } else {
-            const float* cb = cbuf + (size_t)(c & 1) * CH * TB;
-            const int* bo = bo_buf + (size_t)(c & 1) * CH;
-            const int* sh = sh_buf + (size_t)(c & 1) * CH * NTt;
+            const char* base = bufs + (size_t)(c & 1) * chunk_bytes;
+            const float* cost = reinterpret_cast<const float*>(base);
+            const unsigned short* idx = reinterpret_cast<const unsigned short*>(base + idx_off);
+            const unsigned* node = reinterpret_cast<const unsigned*>(base + node_off);
+            double* obest = reinterpret_cast<double*>(obufs + (size_t)(c & 1) * out_bytes);
+            int* okey = reinterpret_cast<int*>(reinterpret_cast<char*>(obest) + dpf_align16((size_t)CH * B * sizeof(double)));
             const int a_end = (a0 + CH) < Aout ? (a0 + CH) : Aout;
-            if (pipelined) {
-                // Software-pipelined sweep: everything of diagonal a+1 that does not depend on csum (band
-                // offsets, lane shifts, ring addresses, costs) is prepared between issuing the ring reads
-                // of diagonal a and consuming them, so the serial chain is ring read -> add/compare ->
-                // group merge -> ring write.
-                int ridx[DPF_TPL], key[DPF_TPL];
-                double cst[DPF_TPL];
-                unsigned okm = 0;
-                int yy = 0, xx = 0;
-                auto prep = [&](int a, int sl, int* r_, int* k_, double* c_, unsigned& ok_, int& yy_, int& xx_) {
-                    const int i = a - a0;
-                    yy_ = b + bo[i];
-                    xx_ = a - yy_;
-                    const bool general = (b < B) && 1 <= xx_ && xx_ <= g.xs && 1 <= yy_ && yy_ <= g.ys && a - 2 < A;
-                    const float* crow = cb + i * TB + b;
-                    const int* shr = sh + i * NTt;
-                    ok_ = 0;
-#pragma unroll
-                    for (int j = 0; j < DPF_TPL; j++) {
-                        const int t = grp + G * j;
-                        const int tc = t < NTt ? t : NTt - 1;
-                        const int pk = tpk[tc];
-                        const int xo = pk & 255, yo = (pk >> 8) & 255, st = pk >> 16;
-                        const int bpv = b + shr[tc];
-                        const bool ok = general && t < NTt && xo <= xx_ && yo <= yy_ && 0 <= bpv && bpv < B;
-                        int ps = sl - st;
-                        ps = ps < 0 ? ps + RD : ps;
-                        r_[j] = ps * B + (ok ? bpv : 0);
-                        k_[j] = (t << 16) | (pk & 0xffff);  // ordered by t; carries (xo, yo) through the merge
-                        c_[j] = (tc >= T) ? pen : (double)crow[tc * B];
-                        ok_ |= ok ? (1u << j) : 0u;
-                    }
-                };
-                prep(a0, slot, ridx, key, cst, okm, yy, xx);
-                for (int a = a0; a < a_end; a++) {
+            const int TB = T * B;
+            struct Part { double tot; int key; };
+            // the type moves of node diagonal a0 + i: this lane's candidates, then the merge across lane groups
+            auto partial = [&](int i) {
+                Part r{inf, 0x7fffffff};
+                if (unrolled) {
                     double pv[DPF_TPL];
-#pragma unroll
-                    for (int j = 0; j < DPF_TPL; j++) pv[j] = ring[ridx[j]];
-                    const int cyy = yy, cxx = xx;
-                    const unsigned cok = okm;
-                    double ccst[DPF_TPL];
-                    int ckey[DPF_TPL];
-#pragma unroll
-                    for (int j = 0; j < DPF_TPL; j++) { ccst[j] = cst[j]; ckey[j] = key[j]; }
-                    const int nslot = (slot + 1 == RD) ? 0 : slot + 1;
-                    if (a + 1 < a_end) prep(a + 1, nslot, ridx, key, cst, okm, yy, xx);
-                    double best = inf;
-                    int bk = 0x7fffffff;
+                    float cs[DPF_TPL];
 #pragma unroll
                     for (int j = 0; j < DPF_TPL; j++) {
-                        const double tot = pv[j] + ccst[j];
-                        if (((cok >> j) & 1u) && tot < best) { best = tot; bk = ckey[j]; }
+                        const int o = i * TB + toff[j];
+                        const int sl = tval[j] ? (int)idx[o] : RD * B;
+                        cs[j] = cost[o];
+                        pv[j] = ring[sl];
                     }
-                    if (G == 4) {
-                        const double ob = xchg16_f64(best, lane);
-                        const int ok2 = (int)xchg16_u32((unsigned)bk, lane);
-                        if (ob < best || (ob == best && ok2 < bk)) { best = ob; bk = ok2; }
+#pragma unroll
+                    for (int j = 0; j < DPF_TPL; j++) {
+                        const double tot = pv[j] + (double)cs[j];
+                        if (tot < r.tot) { r.tot = tot; r.key = tkey[j]; }
                     }
-                    if (G >= 2) {
-                        const double ob = xchg32_f64(best, lane);
-                        const int ok2 = (int)xchg32_u32((unsigned)bk, lane);
-                        if (ob < best || (ob == best && ok2 < bk)) { best = ob; bk = ok2; }
-                    }
-                    if (b < B && grp == 0) {
-                        int bx, by;
-                        if (cxx == 0 && 0 <= cyy && cyy <= g.ys) {
-                            best = pen * (double)cyy; bx = 0; by = 1;
-                        } else if (cyy == 0 && 0 <= cxx && cxx <= g.xs) {
-                            best = pen * (double)cxx; bx = 1; by = 0;
-                        } else if (bk != 0x7fffffff) {
-                            bx = bk & 255; by = (bk >> 8) & 255;
-                        } else {
-                            best = inf; bx = -42; by = -42;
-                        }
-                        ring[slot * B + b] = best;
-                        store_node(g, (size_t)((unsigned)a * (unsigned)B + (unsigned)b), best, bx, by);
-                    }
-                    slot = nslot;
-                    __builtin_amdgcn_wave_barrier();
-                }
-            } else
-            for (int a = a0; a < a_end; a++) {
-                const int i = a - a0;
-                const bool active = b < B;
-                const int yy = b + bo[i];
-                const int xx = a - yy;
-                double best = inf;
-                int bt = 1 << 20;
-                // general node: cost cell (a-2, b) exists (b_offset_out[a] = b_offset_in[a-2] + 1, so bc == b)
-                const bool general = active && 1 <= xx && xx <= g.xs && 1 <= yy && yy <= g.ys && a - 2 < A;
-                if (general) {
-                    const float* crow = cb + i * TB + b;
-                    const int* shr = sh + i * NTt;
-                    for (int t = grp; t < NTt; t += G) {
-                        const int pk = tpk[t];
-                        const int xo = pk & 255, yo = (pk >> 8) & 255, st = pk >> 16;
-                        const int bpv = b + shr[t];
-                        const bool ok = xo <= xx && yo <= yy && 0 <= bpv && bpv < B;
-                        int ps = slot - st;
-                        ps = ps < 0 ? ps + RD : ps;
-                        const double prev = ring[ps * B + (ok ? bpv : 0)];
-                        const double ac_cost = (t >= T) ? pen : (double)crow[t * B];
-                        const double tot = prev + ac_cost;
-                        if (ok && tot < best) { best = tot; bt = t; }
+                } else {
+                    for (int t = grp; t < T; t += G) {
+                        const int o = i * TB + t * B + bb;
+                        const double tot = ring[idx[o]] + (double)cost[o];
+                        if (tot < r.tot) { r.tot = tot; r.key = (t << 16) | (tpk[t] & 0xffff); }
                     }
                 }
-                // merge the groups: smaller total wins, equal totals -> smaller transition index
                 if (G == 4) {
-                    const double ob = xchg16_f64(best, lane);
-                    const int ot = (int)xchg16_u32((unsigned)bt, lane);
-                    if (ob < best || (ob == best && ot < bt)) { best = ob; bt = ot; }
+                    const double ob = xchg16_f64(r.tot, lane);
+                    const int ok2 = (int)xchg16_u32((unsigned)r.key, lane);
+                    if (ob < r.tot || (ob == r.tot && ok2 < r.key)) { r.tot = ob; r.key = ok2; }
                 }
                 if (G >= 2) {
-                    const double ob = xchg32_f64(best, lane);
-                    const int ot = (int)xchg32_u32((unsigned)bt, lane);
-                    if (ob < best || (ob == best && ot < bt)) { best = ob; bt = ot; }
+                    const double ob = xchg32_f64(r.tot, lane);
+                    const int ok2 = (int)xchg32_u32((unsigned)r.key, lane);
+                    if (ob < r.tot || (ob == r.tot && ok2 < r.key)) { r.tot = ob; r.key = ok2; }
                 }
-                if (active && grp == 0) {
-                    int bx, by;
-                    if (xx == 0 && 0 <= yy && yy <= g.ys) {
-                        best = pen * (double)yy; bx = 0; by = 1;
-                    } else if (yy == 0 && 0 <= xx && xx <= g.xs) {
-                        best = pen * (double)xx; bx = 1; by = 0;
-                    } else if (bt < NTt) {
-                        const int pk = tpk[bt];
-                        bx = pk & 255; by = (pk >> 8) & 255;
-                    } else {
-                        best = inf; bx = -42; by = -42;
-                    }
+                return r;
+            };
+            Part part = T > 0 ? partial(0) : Part{inf, 0x7fffffff};
+            unsigned nw = node[bb];
+            for (int a = a0; a < a_end; a++) {
+                const int i = a - a0;
+                const int inext = a + 1 < a_end ? i + 1 : i;  // (the last diagonal re-reads itself: no branch)
+                // stage 1 of diagonal a+1 (independent of what follows)
+                const unsigned nnw = node[inext * B + bb];
+                Part npart{inf, 0x7fffffff};
+                if (T > 0) npart = partial(inext);
+                // stage 2 of diagonal a: the deletions, from the register copy of diagonal a-1
+                const int kind = nw & 3, s01 = (nw >> 2) & 127, s10 = (nw >> 9) & 127;
+                const double p01 = __shfl(cur, gbase + (s01 < B ? s01 : bb), SVX_WAVE);
+                const double p10 = __shfl(cur, gbase + (s10 < B ? s10 : bb), SVX_WAVE);
+                double best = part.tot;
+                int bk = part.key;
+                const double t01 = p01 + pen, t10 = p10 + pen;
+                if (s01 < B && t01 < best) { best = t01; bk = key01; }
+                if (s10 < B && t10 < best) { best = t10; bk = key10; }
+                // borders cost pen * a; nodes outside the lattice and unreachable nodes are +inf / "none"
+                const double border = pen * (double)a;
+                best = kind == 0 ? (bk != 0x7fffffff ? best : inf) : (kind == 3 ? inf : border);
+                bk = kind == 0 ? bk : (kind == 1 ? key01 : (kind == 2 ? key10 : 0x7fffffff));
+                cur = best;
+                if (b < B && grp == 0) {
                     ring[slot * B + b] = best;
-                    store_node(g, (size_t)((unsigned)a * (unsigned)B + (unsigned)b), best, bx, by);
+                    obest[i * B + b] = best;
+                    okey[i * B + b] = bk;
                 }
+                part = npart;
+                nw = nnw;
                 slot = (slot + 1 == RD) ? 0 : slot + 1;
                 __builtin_amdgcn_wave_barrier();
             }
         }
         __syncthreads();
     }
+    {
+        const int a0 = (nchunks - 1) * CH;
+        dpf_flush(g, obufs + (size_t)((nchunks - 1) & 1) * out_bytes, B, CH, a0, Aout, tid, DPF_THREADS);
+    }
+}
+
+template <int TPLT, int G>
+__global__ __launch_bounds__(DPF_THREADS) void k_sparse_dp_fast(SparseDpArgs g, SvxTypes ty, int CH) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    sparse_dp_fast<TPLT, G>(g, ty, CH, smem);
 }
 
 template <bool RING>
 __global__ __launch_bounds__(1024) void k_sparse_dp(SparseDpArgs g, SvxTypes ty) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     sparse_dp_block<RING>(g, ty, reinterpret_cast<double*>(smem));
-}
-
-template <int TPLT>
-__global__ __launch_bounds__(DPF_THREADS) void k_sparse_dp_fast(SparseDpArgs g, SvxTypes ty, int CH) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    sparse_dp_fast<TPLT>(g, ty, CH, smem);
 }
 
 __device__ __forceinline__ bool batch_dp_args(const SvxPairDev& P, int depth, int B, SparseDpArgs* g) {
@@ -503,13 +531,13 @@ __global__ __launch_bounds__(1024) void k_sparse_dp_batch(const SvxPairDev* __re
     sparse_dp_block<RING>(g, ty, reinterpret_cast<double*>(smem));
 }
 
-template <int TPLT>
+template <int TPLT, int G>
 __global__ __launch_bounds__(DPF_THREADS) void k_sparse_dp_fast_batch(const SvxPairDev* __restrict__ pairs, int depth,
                                                                        SvxTypes ty, int B, int CH) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SparseDpArgs g;
     if (!batch_dp_args(pairs[blockIdx.x], depth, B, &g)) return;
-    sparse_dp_fast<TPLT>(g, ty, CH, smem);
+    sparse_dp_fast<TPLT, G>(g, ty, CH, smem);
 }
 
 // ------------------------------------------------------------------------------ band traceback
@@ -972,17 +1000,26 @@ int svxl_dense_traceback(svx_ctx* ctx, const int* bp, int s0, int s1, int* align
 }
 
 // transitions per lane of the pipelined sweep: ceil((T+2)/G) rounded up to an instantiated size, 0 = generic loop
+// lane groups sharing one diagonal: as many as the band width allows, but never more than there are types
+static int dpf_groups(int T, int B) {
+    int G = B <= 16 ? 4 : (B <= 32 ? 2 : 1);
+    while (G > 1 && T < G) G >>= 1;
+    return G;
+}
 static int dpf_tpl(int T, int B) {
-    const int G = B <= 16 ? 4 : (B <= 32 ? 2 : 1);
-    const int t = (T + 2 + G - 1) / G;
+    const int G = dpf_groups(T, B);
+    int t = (T + G - 1) / G;  // alignment types per lane (the two deletions are handled by every lane)
+    if (t < 1) t = 1;
     return t <= 4 ? t : (t <= 6 ? 6 : 0);
 }
 
 static int dpf_choose_ch(int T, int B, int maxstep) {
     if (B > 64 || maxstep > 120) return 0;  // transitions are packed into 8-bit fields
     const int opts[4] = {64, 32, 16, 8};
+    for (int i = 0; i < 3; i++)  // two workgroups per CU when a chunk of >= 16 diagonals allows it
+        if (dpf_smem_bytes(T, B, maxstep + 1, opts[i]) <= 78 * 1024) return opts[i];
     for (int i = 0; i < 4; i++)
-        if (dpf_smem_bytes(T, B, maxstep + 1, opts[i]) <= 120 * 1024) return opts[i];
+        if (dpf_smem_bytes(T, B, maxstep + 1, opts[i]) <= 150 * 1024) return opts[i];
     return 0;
 }
 
@@ -993,20 +1030,26 @@ int svxl_sparse_dp(svx_ctx* ctx, const float* costs, const int* boff_in, int A, 
     const int CH = dpf_choose_ch(types.n, B, types.maxstep);
     if (CH > 0) {
         const size_t smem = dpf_smem_bytes(types.n, B, types.maxstep + 1, CH);
-#define DPF_LAUNCH(TPLT)                                                                                              \
+#define DPF_LAUNCH(TPLT, GG)                                                                                          \
     do {                                                                                                              \
         if (smem > 64 * 1024)                                                                                         \
-            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_dp_fast<TPLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL(k_sparse_dp_fast<TPLT>, dim3(1), dim3(DPF_THREADS), smem, ctx->stream, g, types, CH);      \
+            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_dp_fast<TPLT, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_sparse_dp_fast<TPLT, GG>), dim3(1), dim3(DPF_THREADS), smem, ctx->stream, g, types, CH); \
     } while (0)
+#define DPF_LAUNCH_G(TPLT)                                                                                            \
+    do {                                                                                                              \
+        if (G == 4) DPF_LAUNCH(TPLT, 4); else if (G == 2) DPF_LAUNCH(TPLT, 2); else DPF_LAUNCH(TPLT, 1);               \
+    } while (0)
+        const int G = dpf_groups(types.n, B);
         switch (dpf_tpl(types.n, B)) {
-            case 1: DPF_LAUNCH(1); break;
-            case 2: DPF_LAUNCH(2); break;
-            case 3: DPF_LAUNCH(3); break;
-            case 4: DPF_LAUNCH(4); break;
-            case 6: DPF_LAUNCH(6); break;
-            default: DPF_LAUNCH(0); break;
+            case 1: DPF_LAUNCH_G(1); break;
+            case 2: DPF_LAUNCH_G(2); break;
+            case 3: DPF_LAUNCH_G(3); break;
+            case 4: DPF_LAUNCH_G(4); break;
+            case 6: DPF_LAUNCH_G(6); break;
+            default: DPF_LAUNCH_G(0); break;
         }
+#undef DPF_LAUNCH_G
 #undef DPF_LAUNCH
         SVX_LAUNCH_CHECK(ctx, "k_sparse_dp_fast");
         return SVX_OK;
@@ -1029,20 +1072,26 @@ int svxl_sparse_dp_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int
     const int CH = dpf_choose_ch(types.n, B, types.maxstep);
     if (CH > 0) {
         const size_t smem = dpf_smem_bytes(types.n, B, types.maxstep + 1, CH);
-#define DPF_LAUNCH(TPLT)                                                                                              \
+#define DPF_LAUNCH(TPLT, GG)                                                                                          \
     do {                                                                                                              \
         if (smem > 64 * 1024)                                                                                         \
-            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_dp_fast_batch<TPLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL(k_sparse_dp_fast_batch<TPLT>, dim3(n_pairs), dim3(DPF_THREADS), smem, ctx->stream, pairs, depth, types, B, CH); \
+            SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_dp_fast_batch<TPLT, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_sparse_dp_fast_batch<TPLT, GG>), dim3(n_pairs), dim3(DPF_THREADS), smem, ctx->stream, pairs, depth, types, B, CH); \
     } while (0)
+#define DPF_LAUNCH_G(TPLT)                                                                                            \
+    do {                                                                                                              \
+        if (G == 4) DPF_LAUNCH(TPLT, 4); else if (G == 2) DPF_LAUNCH(TPLT, 2); else DPF_LAUNCH(TPLT, 1);               \
+    } while (0)
+        const int G = dpf_groups(types.n, B);
         switch (dpf_tpl(types.n, B)) {
-            case 1: DPF_LAUNCH(1); break;
-            case 2: DPF_LAUNCH(2); break;
-            case 3: DPF_LAUNCH(3); break;
-            case 4: DPF_LAUNCH(4); break;
-            case 6: DPF_LAUNCH(6); break;
-            default: DPF_LAUNCH(0); break;
+            case 1: DPF_LAUNCH_G(1); break;
+            case 2: DPF_LAUNCH_G(2); break;
+            case 3: DPF_LAUNCH_G(3); break;
+            case 4: DPF_LAUNCH_G(4); break;
+            case 6: DPF_LAUNCH_G(6); break;
+            default: DPF_LAUNCH_G(0); break;
         }
+#undef DPF_LAUNCH_G
 #undef DPF_LAUNCH
         SVX_LAUNCH_CHECK(ctx, "k_sparse_dp_fast_batch");
         return SVX_OK;
