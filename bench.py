@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=512, help="document pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=1024, help="document pairs per GPU per step")
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--d", type=int, default=1024)

@@ -16,6 +16,8 @@
 // fills the chip with pairs.  Sums are float64, ties are broken by the first strictly smaller
 // candidate in transition order, exactly like the reference, so given the same float32 costs the
 // results are bit-identical.
+#include <stdlib.h>
+
 #include "svx_common.h"
 
 namespace {
@@ -541,11 +543,9 @@ __global__ __launch_bounds__(DPF_THREADS) void k_sparse_dp_fast_batch(const SvxP
 }
 
 // ------------------------------------------------------------------------------ band traceback
-// Thread 0 walks the back-pointers from (xs,ys) to (0,0) and writes the alignment rows from the
-// back of the buffer; when they fit, b_offset_out and the packed back-pointers are first copied
-// into LDS so that the pointer chase never leaves the CU.  Then the whole workgroup moves the rows
-// to the front in document order and computes the scores from csum (process_scores).
-// cap = xs + ys + 2 rows / doubles.
+// Thread 0 walks the back-pointers from (xs,ys) to (0,0) out of an LDS window that slides down the diagonals
+// (sparse_traceback_block), then the whole workgroup moves the rows to the front in document order and computes
+// the scores from csum (process_scores).  cap = xs + ys + 2 rows / doubles.
 struct TbArgs {
     const double* csum;
     const int* xp;             // int32 back-pointers, or null when bpk is given
@@ -557,80 +557,121 @@ struct TbArgs {
     double* scores;
     int* count;
     int* status;
-    int use_lds;               // LDS holds boff [Aout] ints, then bp [Aout*B]: bytes (from bpk) or 16-bit (from xp/yp)
+    int chunk;                 // > 0: diagonals per LDS window (two windows of back-pointers + b_offset_out); 0: walk global memory
 };
 
-__host__ __device__ inline size_t tb_bp_bytes(int Aout, int B, bool wide) {
-    return (((size_t)Aout * B * (wide ? 2 : 1)) + 15) & ~(size_t)15;
+// One LDS window = `chunk` diagonals of back-pointers (bytes from bpk, or 16-bit words packed from xp/yp) and
+// of b_offset_out.
+__host__ __device__ inline size_t tb_win_bytes(int chunk, int B, bool wide) {
+    const size_t bp = (size_t)chunk * B * (wide ? 2 : 1);
+    return ((bp + 15) & ~(size_t)15) + (size_t)chunk * sizeof(int);
 }
-__host__ __device__ inline size_t tb_smem_bytes(int Aout, int B, bool wide) {
-    return tb_bp_bytes(Aout, B, wide) + (size_t)Aout * sizeof(int);  // back-pointers first (16-byte aligned), then boff
+__host__ __device__ inline size_t tb_smem_bytes(int chunk, int B, bool wide) { return 2 * tb_win_bytes(chunk, B, wide); }
+// diagonals per window: a multiple of 16 (so that a window of bytes starts 16-byte aligned) within ~20 KB
+__host__ __device__ inline int tb_chunk(int B, bool wide) {
+    const int c = (int)((20 * 1024) / ((size_t)B * (wide ? 2 : 1) + sizeof(int))) & ~15;
+    return c >= 64 ? c : 0;  // very wide bands walk global memory instead
 }
 
+// window j = diagonals [j*chunk, min((j+1)*chunk, Aout)) -> LDS
+__device__ __forceinline__ void tb_load_window(const TbArgs& g, char* win, int j, int tsub, int nsub) {
+    const int B = g.B, lo = j * g.chunk;
+    const int hi = (lo + g.chunk) < g.Aout ? (lo + g.chunk) : g.Aout;
+    const bool wide = g.bpk == nullptr;
+    int* lbo = reinterpret_cast<int*>(win + ((((size_t)g.chunk * B * (wide ? 2 : 1)) + 15) & ~(size_t)15));
+    for (int i = tsub; i < hi - lo; i += nsub) lbo[i] = g.boff[lo + i];
+    const size_t first = (size_t)lo * B, nb = (size_t)(hi - lo) * B;
+    if (!wide) {
+        unsigned char* lbp = reinterpret_cast<unsigned char*>(win);
+        const unsigned char* src = g.bpk + first;
+        if ((reinterpret_cast<size_t>(src) & 15) == 0) {
+            const size_t nv = nb / 16;
+            for (size_t i = tsub; i < nv; i += nsub) reinterpret_cast<uint4*>(lbp)[i] = reinterpret_cast<const uint4*>(src)[i];
+            for (size_t i = nv * 16 + tsub; i < nb; i += nsub) lbp[i] = src[i];
+        } else {
+            for (size_t i = tsub; i < nb; i += nsub) lbp[i] = src[i];
+        }
+    } else {
+        unsigned short* lbw = reinterpret_cast<unsigned short*>(win);
+        for (size_t i = tsub; i < nb; i += nsub) {
+            const int px = g.xp[first + i], py = g.yp[first + i];
+            lbw[i] = (px < 0 || py < 0 || px > 255 || py > 255) ? (unsigned short)0xFFFF : (unsigned short)((px << 8) | py);
+        }
+    }
+}
+
+// Thread 0 walks the back-pointers from (xs,ys) to (0,0) and writes the alignment rows from the back of the
+// buffer.  The walk only ever moves to smaller diagonals, so the back-pointers pass through LDS as a sliding
+// pair of windows: while thread 0 walks window j the other waves fetch window j-1.
 __device__ void sparse_traceback_block(const TbArgs& g, char* smem) {
     __shared__ int sh_n;
     const int cap = g.xs + g.ys + 2;
     const int Aout = g.Aout, B = g.B;
-    unsigned char* lbp = reinterpret_cast<unsigned char*>(smem);
-    unsigned short* lbw = reinterpret_cast<unsigned short*>(lbp);
-    int* lbo = reinterpret_cast<int*>(smem + tb_bp_bytes(Aout, B, g.bpk == nullptr));
-    if (g.use_lds) {
-        for (int i = threadIdx.x; i < Aout; i += blockDim.x) lbo[i] = g.boff[i];
-        const size_t nb = (size_t)Aout * B;
-        if (g.bpk) {
-            // 16-byte copies (the arena keeps bpk 256-byte aligned; the LDS copy starts at offset 0)
-            const size_t nv = nb / 16;
-            if ((reinterpret_cast<size_t>(g.bpk) & 15) == 0) {
-                const uint4* src = reinterpret_cast<const uint4*>(g.bpk);
-                uint4* dst = reinterpret_cast<uint4*>(lbp);
-                for (size_t i = threadIdx.x; i < nv; i += blockDim.x) dst[i] = src[i];
-                for (size_t i = nv * 16 + threadIdx.x; i < nb; i += blockDim.x) lbp[i] = g.bpk[i];
-            } else {
-                for (size_t i = threadIdx.x; i < nb; i += blockDim.x) lbp[i] = g.bpk[i];
-            }
-        } else {
-            for (size_t i = threadIdx.x; i < nb; i += blockDim.x) {
-                const int px = g.xp[i], py = g.yp[i];
-                lbw[i] = (px < 0 || py < 0 || px > 255 || py > 255) ? (unsigned short)0xFFFF : (unsigned short)((px << 8) | py);
-            }
-        }
+    const bool wide = g.bpk == nullptr;
+    const size_t win_bytes = g.chunk > 0 ? tb_win_bytes(g.chunk, B, wide) : 0;
+    const int nwin = g.chunk > 0 ? (Aout + g.chunk - 1) / g.chunk : 1;
+    int xx = g.xs, yy = g.ys, nw = 0, err = 0;  // walk state of thread 0
+    bool done = false;
+    if (g.chunk > 0) {
+        tb_load_window(g, smem + (size_t)((nwin - 1) & 1) * win_bytes, nwin - 1, threadIdx.x, blockDim.x);
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        int xx = g.xs, yy = g.ys, n = 0, err = 0;
-        for (;;) {
-            if (xx == 0 && yy == 0) break;
-            const int aa = xx + yy;
-            if (aa < 0 || aa >= Aout || n >= cap - 1) { err = SVX_ERR_TRACEBACK; break; }
-            const int bb = yy - (g.use_lds ? lbo[aa] : g.boff[aa]);
-            if (bb < 0 || bb >= B) { err = SVX_ERR_TRACEBACK; break; }
-            const size_t o = (size_t)aa * B + bb;
-            int px, py;
-            if (g.bpk) {
-                const unsigned char v = g.use_lds ? lbp[o] : g.bpk[o];
-                px = v == 0xFF ? -42 : (v >> 4);
-                py = v == 0xFF ? -42 : (v & 15);
-            } else if (g.use_lds) {
-                const unsigned short v = lbw[o];
-                px = v == 0xFFFF ? -42 : (v >> 8);
-                py = v == 0xFFFF ? -42 : (v & 255);
-            } else {
-                px = g.xp[o];
-                py = g.yp[o];
+    for (int j = nwin - 1; j >= 0; j--) {
+        if (g.chunk > 0 && j > 0 && threadIdx.x >= 64) tb_load_window(g, smem + (size_t)((j - 1) & 1) * win_bytes, j - 1, threadIdx.x - 64, blockDim.x - 64);
+        if (threadIdx.x == 0 && !done && !err) {
+            const int lo = g.chunk > 0 ? j * g.chunk : 0;
+            const char* win = smem + (size_t)(j & 1) * win_bytes;
+            const unsigned char* lbp = reinterpret_cast<const unsigned char*>(win);
+            const unsigned short* lbw = reinterpret_cast<const unsigned short*>(win);
+            const int* lbo = reinterpret_cast<const int*>(win + ((((size_t)g.chunk * B * (wide ? 2 : 1)) + 15) & ~(size_t)15));
+            for (;;) {
+                if (xx == 0 && yy == 0) { done = true; break; }
+                const int aa = xx + yy;
+                if (aa < lo) break;  // continues in the next window
+                if (aa < 0 || aa >= Aout || nw >= cap - 1) { err = SVX_ERR_TRACEBACK; break; }
+                const int bb = yy - (g.chunk > 0 ? lbo[aa - lo] : g.boff[aa]);
+                if (bb < 0 || bb >= B) { err = SVX_ERR_TRACEBACK; break; }
+                int px, py;
+                if (g.chunk > 0) {
+                    const size_t o = (size_t)(aa - lo) * B + bb;
+                    if (!wide) {
+                        const unsigned char v = lbp[o];
+                        px = v == 0xFF ? -42 : (v >> 4);
+                        py = v == 0xFF ? -42 : (v & 15);
+                    } else {
+                        const unsigned short v = lbw[o];
+                        px = v == 0xFFFF ? -42 : (v >> 8);
+                        py = v == 0xFFFF ? -42 : (v & 255);
+                    }
+                } else {
+                    const size_t o = (size_t)aa * B + bb;
+                    if (g.bpk) {
+                        const unsigned char v = g.bpk[o];
+                        px = v == 0xFF ? -42 : (v >> 4);
+                        py = v == 0xFF ? -42 : (v & 15);
+                    } else {
+                        px = g.xp[o];
+                        py = g.yp[o];
+                    }
+                }
+                if (px < 0 || py < 0 || (px == 0 && py == 0) || px > xx || py > yy) { err = SVX_ERR_TRACEBACK; break; }
+                *reinterpret_cast<int4*>(g.align + 4 * (size_t)(cap - 1 - nw)) = make_int4(xx - px, px, yy - py, py);
+                xx -= px;
+                yy -= py;
+                nw++;
             }
-            if (px < 0 || py < 0 || (px == 0 && py == 0) || px > xx || py > yy) { err = SVX_ERR_TRACEBACK; break; }
-            int* r = g.align + 4 * (size_t)(cap - 1 - n);
-            r[0] = xx - px; r[1] = px; r[2] = yy - py; r[3] = py;
-            xx -= px;
-            yy -= py;
-            n++;
         }
+        if (g.chunk > 0) __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (!err && !done) err = SVX_ERR_TRACEBACK;
+
         if (!err) {  // the end node itself must be inside the band (the reference indexes it first)
             const int aa = g.xs + g.ys;
             const int bb = (aa >= 0 && aa < Aout) ? g.ys - g.boff[aa] : -1;
             if (bb < 0 || bb >= B) err = SVX_ERR_TRACEBACK;
         }
-        sh_n = err ? -err : n;
+        sh_n = err ? -err : nw;
     }
     __syncthreads();
     const int n = sh_n;
@@ -675,7 +716,7 @@ __global__ __launch_bounds__(256) void k_sparse_traceback(TbArgs g) {
 }
 
 __global__ __launch_bounds__(256) void k_sparse_traceback_batch(const SvxPairDev* __restrict__ pairs, int depth, int B,
-                                                                int lds_cap_aout) {
+                                                                int chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SvxPairDev& P = pairs[blockIdx.x];
     if (depth > P.L || (depth == P.L && P.L > 0)) return;
@@ -687,7 +728,7 @@ __global__ __launch_bounds__(256) void k_sparse_traceback_batch(const SvxPairDev
     g.csum = Lv.csum; g.xp = Lv.xp; g.yp = Lv.yp; g.bpk = Lv.bpk; g.boff = Lv.boff_out;
     g.Aout = A + 2; g.B = B; g.xs = Lv.n[0]; g.ys = Lv.n[1];
     g.align = Lv.align; g.scores = Lv.scores; g.count = Lv.n_align; g.status = P.status;
-    g.use_lds = (A + 2) <= lds_cap_aout;
+    g.chunk = chunk;
     sparse_traceback_block(g, smem);
 }
 
@@ -1016,8 +1057,12 @@ static int dpf_tpl(int T, int B) {
 static int dpf_choose_ch(int T, int B, int maxstep) {
     if (B > 64 || maxstep > 120) return 0;  // transitions are packed into 8-bit fields
     const int opts[4] = {64, 32, 16, 8};
-    for (int i = 0; i < 3; i++)  // two workgroups per CU when a chunk of >= 16 diagonals allows it
-        if (dpf_smem_bytes(T, B, maxstep + 1, opts[i]) <= 78 * 1024) return opts[i];
+    // The sweep is latency-bound, so what matters is how many pairs a CU can host at once: four workgroups
+    // (<= 36 KB of LDS each) if a chunk of >= 16 diagonals allows it, else three.
+    for (int i = 0; i < 3; i++)
+        if (dpf_smem_bytes(T, B, maxstep + 1, opts[i]) <= 36 * 1024) return opts[i];
+    for (int i = 0; i < 3; i++)
+        if (dpf_smem_bytes(T, B, maxstep + 1, opts[i]) <= 52 * 1024) return opts[i];
     for (int i = 0; i < 4; i++)
         if (dpf_smem_bytes(T, B, maxstep + 1, opts[i]) <= 150 * 1024) return opts[i];
     return 0;
@@ -1109,7 +1154,6 @@ int svxl_sparse_dp_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int
     return SVX_OK;
 }
 
-static const size_t TB_LDS_LIMIT = 150 * 1024;
 
 int svxl_sparse_traceback(svx_ctx* ctx, const double* csum, const int* xp, const int* yp, const int* boff, int a_out, int B,
                           int xs, int ys, int* align, double* scores, int* count) {
@@ -1117,9 +1161,8 @@ int svxl_sparse_traceback(svx_ctx* ctx, const double* csum, const int* xp, const
     g.csum = csum; g.xp = xp; g.yp = yp; g.bpk = nullptr; g.boff = boff;
     g.Aout = a_out; g.B = B; g.xs = xs; g.ys = ys;
     g.align = align; g.scores = scores; g.count = count; g.status = nullptr;
-    size_t smem = tb_smem_bytes(a_out, B, true);
-    g.use_lds = smem <= TB_LDS_LIMIT;
-    if (!g.use_lds) smem = 0;
+    g.chunk = tb_chunk(B, true);
+    const size_t smem = g.chunk > 0 ? tb_smem_bytes(g.chunk, B, true) : 0;
     if (smem > 64 * 1024)
         SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_traceback, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(k_sparse_traceback, dim3(1), dim3(256), smem, ctx->stream, g);
@@ -1129,15 +1172,12 @@ int svxl_sparse_traceback(svx_ctx* ctx, const double* csum, const int* xp, const
 
 int svxl_sparse_traceback_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int depth, int B, int max_A, int packed) {
     if (n_pairs <= 0) return SVX_OK;
-    // LDS for the largest pair that still fits; larger pairs in the batch chase pointers in global memory
-    // (pairs whose types do not pack into bytes hold 16-bit entries: budget for those)
-    int cap_aout = (int)(TB_LDS_LIMIT / (sizeof(int) + 2 * (size_t)B));
-    if (packed) cap_aout = (int)(TB_LDS_LIMIT / (sizeof(int) + (size_t)B));
-    if (cap_aout > max_A + 2) cap_aout = max_A + 2;
-    const size_t smem = tb_smem_bytes(cap_aout, B, !packed);
+    const int chunk = tb_chunk(B, !packed);
+    const size_t smem = chunk > 0 ? tb_smem_bytes(chunk, B, !packed) : 0;
+    (void)max_A;
     if (smem > 64 * 1024)
         SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_traceback_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(k_sparse_traceback_batch, dim3(n_pairs), dim3(256), smem, ctx->stream, pairs, depth, B, cap_aout);
+    hipLaunchKernelGGL(k_sparse_traceback_batch, dim3(n_pairs), dim3(256), smem, ctx->stream, pairs, depth, B, chunk);
     SVX_LAUNCH_CHECK(ctx, "k_sparse_traceback_batch");
     return SVX_OK;
 }
