@@ -517,6 +517,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         if (top.n[0] > max_ds0) max_ds0 = top.n[0];
         if (top.n[1] > max_ds1) max_ds1 = top.n[1];
         OFF(P.dcost, (size_t)top.n[0] * top.n[1] * sizeof(float));
+        OFF(P.ddot, (size_t)top.n[0] * top.n[1] * sizeof(float));
         OFF(P.dbp, (size_t)(top.n[0] + 1) * (top.n[1] + 1) * sizeof(int));
     }
 #undef OFF
@@ -545,6 +546,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             if (l > 0) { patch(Lv.align); patch(Lv.scores); patch(Lv.n_align); }
         }
         patch(P.dcost);
+        patch(P.ddot);
         patch(P.dbp);
     }
     SvxPairDev* dpairs = reinterpret_cast<SvxPairDev*>(base + o_desc);
@@ -567,6 +569,12 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             if ((rc2 = svxl_pyramid_level(ctx, dp, np, l, dtype, d, max_nblk[l], max_ksum, 1))) return rc2;
         }
         {
+            // coarsest level: the dense 1-1 cost matrix, and with it the dot products its sampled scores need
+            StageScope sc(ctx, S_DENSE_COSTS);
+            if ((rc2 = svxl_dense_costs_batch(ctx, dp, np, max_ds0, max_ds1, dtype, d))) return rc2;
+            if ((rc2 = svxl_knob_from_dots(ctx, dp, np, max_kn))) return rc2;
+        }
+        {
             StageScope sc(ctx, S_KNOB_SORT);
             if ((rc2 = svxl_knob_scores(ctx, dp, np, maxL, max_kn, max_n0, dtype, d, 0))) return rc2;
         }
@@ -583,10 +591,6 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         {
             StageScope sc(ctx, S_KNOB);
             if ((rc2 = svxl_del_penalty_batch(ctx, dp, np, maxL + 1, prm->del_percentile_frac))) return rc2;
-        }
-        {
-            StageScope sc(ctx, S_DENSE_COSTS);
-            if ((rc2 = svxl_dense_costs_batch(ctx, dp, np, max_ds0, max_ds1, dtype, d))) return rc2;
         }
         {
             StageScope sc(ctx, S_DENSE_DP);

@@ -116,6 +116,7 @@ struct SvxPairDev {
     int d;
     int norm_override[2];
     float* dcost;      // dense stage at level L: [s0][s1]
+    float* ddot;       // [s0][s1] raw dot products of the same stage (L >= 1): the level's sampled scores read them
     int* dbp;          // [s0+1][s1+1]
     int* status;       // info[1]
     SvxLevel lev[SVX_MAX_LEVELS];
@@ -170,6 +171,7 @@ int svxl_knob_scores(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_lev
 int svxl_dense_costs(svx_ctx*, const float* v0, int s0, const float* v1, int s1, int d, const float* n0,
                      const float* n1, int mul0, int mul1, float* costs);
 int svxl_dense_costs_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_s0, int max_s1, int dtype, int d);
+int svxl_knob_from_dots(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_kn);
 int svxl_band_costs(svx_ctx*, const void* v0, int k0, int n, const void* v1, int k1, int m, int d, int dtype,
                     const float* inv0, const float* inv1, const float* nrm0, const float* nrm1, const int* path,
                     int A, const SvxTypes& types, int W, float* costs, int* boff, int* status);

@@ -98,6 +98,7 @@ struct DenseArgs {
     const float* n1;
     int mul0, mul1;  // (offset0+1), (offset1+1)
     float* costs;    // [s0][s1]
+    float* dots;     // optional [s0][s1]: the normalised dot products themselves
 };
 
 template <typename E>
@@ -136,6 +137,7 @@ __device__ void dense_block(const DenseArgs& g, int bx, int by, char* smem) {
             float c = cost_formula(sumx, 1, 1, g.n0[x], g.n1[y]);
             c = (c * (float)g.mul0) * (float)g.mul1;  // dp_core.pyx:75 (float * int)
             g.costs[(size_t)x * g.s1 + y] = c;
+            if (g.dots) g.dots[(size_t)x * g.s1 + y] = sumx;
         }
     }
 }
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(256) void k_dense_costs_batch(const SvxPairDev* __r
     g.mul0 = 1;
     g.mul1 = 1;
     g.costs = P.dcost;
+    g.dots = LV0 ? nullptr : P.ddot;
     dense_block<E>(g, blockIdx.x, blockIdx.y, smem);
 }
 
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restric
     const SvxPairDev& P = pairs[task / nlev];
     const int level = task % nlev + (LV0 ? 0 : 1);
     if (level > P.L) return;
+    if (!LV0 && level == P.L) return;  // the coarsest level's samples read the dense stage's dots (k_knob_from_dots)
     const SvxLevel& Lv = P.lev[level];
     const int lane = threadIdx.x & 63;
     const int n = Lv.n[0], m = Lv.n[1], d = P.d;
@@ -333,6 +337,23 @@ __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restric
                 Lv.kscore[i] = (float)((2.0 * (1.0 - (double)dot)) / (double)den);
             }
         }
+    }
+}
+
+// Sampled scores of the coarsest level (L >= 1): score_path (dp_core.pyx:143-161) from the dot products that the
+// dense cost stage of the same level has just computed on the matrix cores -- no row is read again.
+__global__ __launch_bounds__(256) void k_knob_from_dots(const SvxPairDev* __restrict__ pairs) {
+    const SvxPairDev& P = pairs[blockIdx.y];
+    if (P.L < 1) return;
+    const SvxLevel& Lv = P.lev[P.L];
+    const int n = Lv.n[0], m = Lv.n[1];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Lv.kn; i += gridDim.x * 256) {
+        int x = Lv.kx[i], y = Lv.ky[i];
+        x = x < 0 ? 0 : (x >= n ? n - 1 : x);
+        y = y < 0 ? 0 : (y >= m ? m - 1 : y);
+        const float dot = P.ddot[(size_t)x * m + y];
+        const float den = Lv.nrm[0][x] + Lv.nrm[1][y];  // float add, no epsilon (dp_core.pyx:161)
+        Lv.kscore[i] = (float)((2.0 * (1.0 - (double)dot)) / (double)den);
     }
 }
 
@@ -713,7 +734,7 @@ constexpr size_t DENSE_SMEM = 64 * sizeof(char*) + 64 * RS;
 int svxl_dense_costs(svx_ctx* ctx, const float* v0, int s0, const float* v1, int s1, int d, const float* n0,
                      const float* n1, int mul0, int mul1, float* costs) {
     if (s0 <= 0 || s1 <= 0) return SVX_OK;
-    DenseArgs g{v0, v1, s0, s1, d, nullptr, nullptr, n0, n1, mul0, mul1, costs};
+    DenseArgs g{v0, v1, s0, s1, d, nullptr, nullptr, n0, n1, mul0, mul1, costs, nullptr};
     hipLaunchKernelGGL(k_dense_costs<ElemF32>, dim3((s0 + 31) / 32, (s1 + 31) / 32), dim3(256), DENSE_SMEM, ctx->stream, g);
     SVX_LAUNCH_CHECK(ctx, "k_dense_costs");
     return SVX_OK;
@@ -749,6 +770,15 @@ int svxl_score_path(svx_ctx* ctx, const int* xx, const int* yy, int64_t n, const
     }
 #undef M
     SVX_LAUNCH_CHECK(ctx, "k_score_path");
+    return SVX_OK;
+}
+
+int svxl_knob_from_dots(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int max_kn) {
+    if (n_pairs <= 0 || max_kn <= 0) return SVX_OK;
+    int nb = (max_kn + 255) / 256;
+    if (nb > 16) nb = 16;
+    hipLaunchKernelGGL(k_knob_from_dots, dim3(nb, n_pairs), dim3(256), 0, ctx->stream, pairs);
+    SVX_LAUNCH_CHECK(ctx, "k_knob_from_dots");
     return SVX_OK;
 }
 
