@@ -194,8 +194,8 @@ def main():
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))["hbm_bytes_per_pair_per_launch"]
                 pat = {"pyr0": r"k_pyramid<.*true>", "pyrN": r"k_pyramid<ElemF32, \d+, false>", "knob_scores0": r"k_knob_scores<.*true>",
                        "knob_scoresN": r"k_knob_scores<ElemF32, \d+, false>", "band_costs0": r"k_band_costs_batch<.*true",
-                       "band_costsN": r"k_band_costs_batch<ElemF32, false", "band_dp0": r"k_sparse_dp_fast_batch<3>",
-                       "band_dpN": r"k_sparse_dp_fast_batch<1>"}[dom]
+                       "band_costsN": r"k_band_costs_batch<ElemF32, false", "band_dp0": r"k_sparse_dp_fast_batch<3, 4>",
+                       "band_dpN": r"k_sparse_dp_fast_batch<1, 1>"}[dom]
                 hit = [v for k, v in tj.items() if re.match(pat, k)]
                 if hit and args.dtype == "bf16" and (N, M, K, d) == (4096, 4096, 4, 1024):
                     traffic = hit[0] * P
