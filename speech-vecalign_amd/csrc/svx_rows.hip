@@ -111,55 +111,56 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
     float cs[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; e++) cs[e] = 0.f;
-    const int nslots = (n + 1) / 2;
     const int slot0 = blk * SVX_PYR_SLOTS + w * (SVX_PYR_SLOTS / 4);
+    const int r0 = 2 * slot0;
+    int r1 = r0 + 2 * (SVX_PYR_SLOTS / 4);   // this wave's rows: [r0, r1)
+    r1 = r1 < n ? r1 : n;
+    float xs[EPL];   // running pair sum
+    float xn[EPL];   // the next row, in flight while the current one is processed
+    if (r0 < r1) R::load(rows + (size_t)r0 * d, d, lane, xn);
 #pragma unroll 1
-    for (int i = 0; i < SVX_PYR_SLOTS / 4; i++) {
-        const int jp = slot0 + i;
-        if (jp >= nslots) break;  // wave-uniform
-        float xs[EPL];            // running pair sum
-#pragma unroll 1
-        for (int half = 0; half < 2; half++) {
-            const int r = 2 * jp + half;
-            if (r >= n) break;  // wave-uniform; only the odd tail row has no partner
-            float x[EPL];
-            R::load(rows + (size_t)r * d, d, lane, x);
-            if (mean) {
-                float mu[EPL];
-                R::loadf(mu_l, DP, lane, mu);
+    for (int r = r0; r < r1; r++) {
+        const int jp = r >> 1, half = r & 1;
+        float x[EPL];
 #pragma unroll
-                for (int e = 0; e < EPL; e++) x[e] = x[e] - mu[e];  // columns >= d: 0 - 0
-            }
-            float ss = 0.f;
+        for (int e = 0; e < EPL; e++) x[e] = xn[e];
+        if (r + 1 < r1) R::load(rows + (size_t)(r + 1) * d, d, lane, xn);
+        if (mean) {
+            float mu[EPL];
+            R::loadf(mu_l, DP, lane, mu);
 #pragma unroll
-            for (int e = 0; e < EPL; e++) ss += x[e] * x[e];
-            ss = wave_sum(ss);
-            const float den = sqrtf(ss) + 1e-5f;
+            for (int e = 0; e < EPL; e++) x[e] = x[e] - mu[e];  // columns >= d: 0 - 0
+        }
+        float ss = 0.f;
 #pragma unroll
-            for (int e = 0; e < EPL; e++) x[e] = x[e] / den;
-            if (rbar) {
-                float rb[EPL];
-                R::loadf(rb_l, DP, lane, rb);
-                float dt = 0.f;
+        for (int e = 0; e < EPL; e++) ss += x[e] * x[e];
+        ss = wave_sum(ss);
+        const float den = sqrtf(ss) + 1e-5f;
+        const float rden = 1.0f / den;  // one division per row; the elements are scaled by the reciprocal
 #pragma unroll
-                for (int e = 0; e < EPL; e++) dt += x[e] * rb[e];
-                dt = wave_sum(dt);
-                if (lane == 0 && nrm_out) nrm_out[r] = 1.0f - dt;
-            }
-            if (lane == 0 && inv_out) inv_out[r] = 1.0f / den;
-            if (vn_out) R::storef(vn_out + (size_t)r * d, d, lane, x);
-            if (next) {
-                if (half == 0) {
+        for (int e = 0; e < EPL; e++) x[e] = x[e] * rden;
+        if (rbar) {
+            float rb[EPL];
+            R::loadf(rb_l, DP, lane, rb);
+            float dt = 0.f;
 #pragma unroll
-                    for (int e = 0; e < EPL; e++) xs[e] = x[e];
-                } else {
+            for (int e = 0; e < EPL; e++) dt += x[e] * rb[e];
+            dt = wave_sum(dt);
+            if (lane == 0 && nrm_out) nrm_out[r] = 1.0f - dt;
+        }
+        if (lane == 0 && inv_out) inv_out[r] = rden;
+        if (vn_out) R::storef(vn_out + (size_t)r * d, d, lane, x);
+        if (next) {
+            if (half == 0) {
 #pragma unroll
-                    for (int e = 0; e < EPL; e++) {
-                        xs[e] = xs[e] + x[e];
-                        cs[e] += xs[e];
-                    }
-                    R::storef_nt(next + (size_t)jp * d, d, lane, xs);
+                for (int e = 0; e < EPL; e++) xs[e] = x[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    xs[e] = xs[e] + x[e];
+                    cs[e] += xs[e];
                 }
+                R::storef_nt(next + (size_t)jp * d, d, lane, xs);
             }
         }
     }
