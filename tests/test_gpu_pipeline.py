@@ -168,6 +168,34 @@ def test_sakoe_chiba_band_vs_oracle(orc):
     assert np.abs(sc_g - sc_o).max() < SCORE_TOL
 
 
+def test_dense_mode_vs_oracle(orc):
+    """SURVEY 8(a) Mode B: the band is wider than the documents (W >= max(N, M) + 1), so every (x, y, type) cell
+    of the lattice is evaluated -- the same kernels with B = 2W cells per diagonal.  Checked against the oracle's
+    make_sparse_costs / sparse_dp / sparse_traceback on the same straight path, and against the coarse-to-fine
+    result (the dense optimum is the global optimum; on this pair the banded search finds it too)."""
+    from svx.vecalign import dp_utils
+    N, M, K = 150, 137, 3
+    W = max(N, M) + 1
+    v0, v1 = make_pair(N, M, K, 64, 77, deletions=9)
+    types = alignment_types(4)
+    a, b = v0.copy(), v1.copy()
+    orc.make_norm1(a)
+    orc.make_norm1(b)
+    rs = np.random.RandomState(23)
+    n0, n1 = orc.compute_norms(a, b, 100, rs), orc.compute_norms(b, a, 100, rs)
+    pen, _ = orc.make_del_penalty(a[0], b[0], n0[0], n1[0], 20000, 0.2, rs)
+    path = orc.search_path([(list(range(N)), list(range(M)))], False, N, M)
+    f, bo = orc.make_sparse_costs(a, b, n0, n1, path, types, W)
+    al_o, sc_o = orc.sparse_traceback(*orc.sparse_dp(f, bo, types, pen, N, M), N, M)
+    np.random.seed(23)
+    al_g, sc_g = dp_utils.align_band(v0, v1, types, 0.2, W, 20000, 100)
+    assert al_g == al_o
+    assert np.abs(sc_g - sc_o).max() < SCORE_TOL
+    np.random.seed(23)
+    st = dp_utils.vecalign(v0, v1, types, 0.2, 7, 300, 20000, 100)
+    assert st[0]['final_alignments'] == al_g
+
+
 def test_sakoe_chiba_full_size_equals_coarse_to_fine():
     """BASELINE configs[3] at full size -- N = M = 32768, d = 1024, band 2048 around the straight diagonal
     (no CPU implementation finishes this in test time: 2.7e9 cost cells).  Size-independent property instead:
