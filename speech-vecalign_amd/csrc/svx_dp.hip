@@ -145,61 +145,82 @@ __device__ __forceinline__ void store_node(const SparseDpArgs& g, size_t o, doub
     if (g.bpk) g.bpk[o] = bx < 0 ? (unsigned char)0xFF : (unsigned char)((bx << 4) | by);
 }
 
-// Generic kernel: any band width, cells strided over the workgroup, costs read straight from
-// global memory.  RING: the last maxstep+1 diagonals of csum live in LDS, else they are re-read
-// from the csum output array.
+// Generic kernel: any band width, cells strided over the workgroup, costs read straight from global memory.
+// RING: the last maxstep+1 diagonals of csum live in LDS, else they are re-read from the csum output array
+// (the workgroup's own stores: one CU, one L1).  Everything that is the same for all cells of a diagonal --
+// b_offset_out[a], the cell shift and the ring slot of each move -- is tabulated for WIDE_CH diagonals at a
+// time, and a cell's moves are relaxed without branches (clamped addresses), so that their loads are in flight
+// together instead of one L2 round trip after the other.
+constexpr int WIDE_CH = 32;
+__host__ __device__ inline size_t wide_tab_bytes(int NTt) { return (size_t)WIDE_CH * (2 * NTt + 1) * sizeof(int) + (size_t)NTt * sizeof(int); }
+
 template <bool RING>
-__device__ void sparse_dp_block(const SparseDpArgs& g, const SvxTypes& ty, double* ring) {
+__device__ void sparse_dp_block(const SparseDpArgs& g, const SvxTypes& ty, double* ring, int* tab) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int A = g.A, B = g.B, Aout = g.A + 2;
     const int T = ty.n, NTt = ty.n + 2;
     const int RD = ty.maxstep + 1;
     const int x_out = g.xs + 1, y_out = g.ys + 1;
+    int* tpk = tab;                       // [NTt] xo | yo << 8 | step << 16
+    int* shs = tab + NTt;                 // [WIDE_CH][NTt] cell shift of move t on diagonal a0 + i
+    int* sls = shs + WIDE_CH * NTt;       // [WIDE_CH][NTt] ring slot (RING) of diagonal a - step
+    int* bos = sls + WIDE_CH * NTt;       // [WIDE_CH] b_offset_out
+    for (int t = tid; t < NTt; t += nt) tpk[t] = (int)ty.x[t] | ((int)ty.y[t] << 8) | (((int)ty.x[t] + (int)ty.y[t]) << 16);
     for (int a = tid; a < Aout; a += nt) g.boff_out[a] = a < 2 ? g.boff_in[0] : g.boff_in[a - 2] + 1;
     __syncthreads();
     const double inf = __builtin_inf();
-    for (int a = 0; a < Aout; a++) {
-        const int bo = g.boff_out[a];
-        for (int b = tid; b < B; b += nt) {
-            const size_t o = (size_t)a * B + b;
-            const int yy = b + bo;
-            const int xx = a - yy;
-            double best;
-            int bx, by;
-            if (xx == 0 && 0 <= yy && yy < y_out) {
-                best = g.pen * (double)yy; bx = 0; by = 1;
-            } else if (yy == 0 && 0 <= xx && xx < x_out) {
-                best = g.pen * (double)xx; bx = 1; by = 0;
-            } else {
-                best = inf; bx = -42; by = -42;
-                const int xc = xx - 1, yc = yy - 1;
-                if (0 <= xc && xc < g.xs && 0 <= yc && yc < g.ys) {
-                    const int ac = xc + yc;
-                    if (ac < A) {  // ac >= 0 here
-                        const int bc = yc - g.boff_in[ac];
-                        if (0 <= bc && bc < B) {
-                            for (int t = 0; t < NTt; t++) {
-                                const int xo = ty.x[t], yo = ty.y[t];
-                                const int xpv = xx - xo, ypv = yy - yo;
-                                if (0 <= xpv && xpv < x_out && 0 <= ypv && ypv < y_out) {
-                                    const int ap = xpv + ypv;  // 0 <= ap < a
-                                    const int bpv = ypv - g.boff_out[ap];
-                                    if (0 <= bpv && bpv < B) {
-                                        const double ac_cost = (t >= T) ? g.pen : (double)g.costs[cost_index(g, T, t, ac, bc)];
-                                        const double prev = RING ? ring[(size_t)(ap % RD) * B + bpv] : g.csum[(size_t)ap * B + bpv];
-                                        const double tot = prev + ac_cost;
-                                        if (tot < best) { best = tot; bx = xo; by = yo; }
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
+    for (int a0 = 0; a0 < Aout; a0 += WIDE_CH) {
+        for (int e = tid; e < WIDE_CH * NTt; e += nt) {
+            const int i = e / NTt, t = e - i * NTt;
+            const int a = a0 + i, st = tpk[t] >> 16, yo = (tpk[t] >> 8) & 255;
+            const int ap = a - st;
+            int v = 1 << 24, sl = 0;  // no predecessor diagonal: the shift pushes the cell out of the band
+            if (a < Aout && ap >= 0) {
+                v = g.boff_out[a] - yo - g.boff_out[ap];
+                sl = ap % RD;
             }
-            if (RING) ring[(size_t)(a % RD) * B + b] = best;
-            store_node(g, o, best, bx, by);
+            shs[e] = v;
+            sls[e] = sl;
         }
+        for (int i = tid; i < WIDE_CH; i += nt) bos[i] = a0 + i < Aout ? g.boff_out[a0 + i] : 0;
         __syncthreads();
+        const int a_end = a0 + WIDE_CH < Aout ? a0 + WIDE_CH : Aout;
+        for (int a = a0; a < a_end; a++) {
+            const int i = a - a0;
+            const int bo = bos[i];
+            const int* sh = shs + i * NTt;
+            const int* sl = sls + i * NTt;
+            const int ac = a - 2;
+            for (int b = tid; b < B; b += nt) {
+                const size_t o = (size_t)a * B + b;
+                const int yy = b + bo;
+                const int xx = a - yy;
+                // general node: the cost cell (xx-1, yy-1) exists; its band index is b (b_offset_out[a] = b_offset_in[a-2] + 1)
+                const bool general = 1 <= xx && xx < x_out && 1 <= yy && yy < y_out && ac < A;
+                double best = inf;
+                int bx = -42, by = -42;
+#pragma unroll 6
+                for (int t = 0; t < NTt; t++) {
+                    const int pk = tpk[t];
+                    const int xo = pk & 255, yo = (pk >> 8) & 255, st = pk >> 16;
+                    const int bpv = b + sh[t];
+                    const bool ok = general && xo <= xx && yo <= yy && 0 <= bpv && bpv < B;
+                    const size_t ci = (ok && t < T) ? cost_index(g, T, t, ac, b) : 0;
+                    const double ac_cost = t < T ? (double)g.costs[ci] : g.pen;
+                    const double prev = RING ? ring[ok ? sl[t] * B + bpv : 0] : g.csum[ok ? (size_t)(a - st) * B + bpv : 0];
+                    const double tot = prev + ac_cost;
+                    if (ok && tot < best) { best = tot; bx = xo; by = yo; }
+                }
+                if (xx == 0 && 0 <= yy && yy < y_out) {
+                    best = g.pen * (double)yy; bx = 0; by = 1;
+                } else if (yy == 0 && 0 <= xx && xx < x_out) {
+                    best = g.pen * (double)xx; bx = 1; by = 0;
+                }
+                if (RING) ring[(size_t)(a % RD) * B + b] = best;
+                store_node(g, o, best, bx, by);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -501,7 +522,8 @@ __global__ __launch_bounds__(DPF_THREADS) void k_sparse_dp_fast(SparseDpArgs g, 
 template <bool RING>
 __global__ __launch_bounds__(1024) void k_sparse_dp(SparseDpArgs g, SvxTypes ty) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    sparse_dp_block<RING>(g, ty, reinterpret_cast<double*>(smem));
+    const size_t ring_bytes = RING ? (((size_t)(ty.maxstep + 1) * g.B * sizeof(double) + 15) & ~(size_t)15) : 0;
+    sparse_dp_block<RING>(g, ty, reinterpret_cast<double*>(smem), reinterpret_cast<int*>(smem + ring_bytes));
 }
 
 __device__ __forceinline__ bool batch_dp_args(const SvxPairDev& P, int depth, int B, SparseDpArgs* g) {
@@ -530,7 +552,8 @@ __global__ __launch_bounds__(1024) void k_sparse_dp_batch(const SvxPairDev* __re
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SparseDpArgs g;
     if (!batch_dp_args(pairs[blockIdx.x], depth, B, &g)) return;
-    sparse_dp_block<RING>(g, ty, reinterpret_cast<double*>(smem));
+    const size_t ring_bytes = RING ? (((size_t)(ty.maxstep + 1) * g.B * sizeof(double) + 15) & ~(size_t)15) : 0;
+    sparse_dp_block<RING>(g, ty, reinterpret_cast<double*>(smem), reinterpret_cast<int*>(smem + ring_bytes));
 }
 
 template <int TPLT, int G>
@@ -1099,14 +1122,16 @@ int svxl_sparse_dp(svx_ctx* ctx, const float* costs, const int* boff_in, int A, 
         SVX_LAUNCH_CHECK(ctx, "k_sparse_dp_fast");
         return SVX_OK;
     }
-    const size_t smem = (size_t)(types.maxstep + 1) * B * sizeof(double);
+    const size_t ring = (((size_t)(types.maxstep + 1) * B * sizeof(double)) + 15) & ~(size_t)15;
+    const size_t tabs = wide_tab_bytes(types.n + 2);
     const int nt = dp_threads(B);
-    if (smem <= 150 * 1024) {
+    if (ring + tabs <= 150 * 1024) {
+        const size_t smem = ring + tabs;
         if (smem > 64 * 1024)
             SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(k_sparse_dp<true>, dim3(1), dim3(nt), smem, ctx->stream, g, types);
     } else {
-        hipLaunchKernelGGL(k_sparse_dp<false>, dim3(1), dim3(nt), 0, ctx->stream, g, types);
+        hipLaunchKernelGGL(k_sparse_dp<false>, dim3(1), dim3(nt), tabs, ctx->stream, g, types);
     }
     SVX_LAUNCH_CHECK(ctx, "k_sparse_dp");
     return SVX_OK;
@@ -1141,14 +1166,16 @@ int svxl_sparse_dp_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int
         SVX_LAUNCH_CHECK(ctx, "k_sparse_dp_fast_batch");
         return SVX_OK;
     }
-    const size_t smem = (size_t)(types.maxstep + 1) * B * sizeof(double);
+    const size_t ring = (((size_t)(types.maxstep + 1) * B * sizeof(double)) + 15) & ~(size_t)15;
+    const size_t tabs = wide_tab_bytes(types.n + 2);
     const int nt = dp_threads(B);
-    if (smem <= 150 * 1024) {
+    if (ring + tabs <= 150 * 1024) {
+        const size_t smem = ring + tabs;
         if (smem > 64 * 1024)
             SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_dp_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(k_sparse_dp_batch<true>, dim3(n_pairs), dim3(nt), smem, ctx->stream, pairs, depth, types, B);
     } else {
-        hipLaunchKernelGGL(k_sparse_dp_batch<false>, dim3(n_pairs), dim3(nt), 0, ctx->stream, pairs, depth, types, B);
+        hipLaunchKernelGGL(k_sparse_dp_batch<false>, dim3(n_pairs), dim3(nt), tabs, ctx->stream, pairs, depth, types, B);
     }
     SVX_LAUNCH_CHECK(ctx, "k_sparse_dp_batch");
     return SVX_OK;
