@@ -168,8 +168,10 @@ def main():
         Bw = 2 * W
         row0 = d * esz
         alg = {
-            "pyr0": K * (N + M) * row0 + (K * (sizes[1][0] + sizes[1][1]) * d * 4 if L >= 1 else 0),
-            "pyrN": sum(K * (a + b) * d * 4 + (a + b) * d * 4 + (K * (sizes[l + 1][0] + sizes[l + 1][1]) * d * 4 if l < L else 0)
+            # level 0 only reads the inputs (norms, column sums); level 1 re-reads them and forms its rows on the fly
+            "pyr0": K * (N + M) * row0,
+            "pyrN": sum((K * (N + M) * row0 if l == 1 else K * (a + b) * d * 4) + (a + b) * d * 4 +
+                        (K * (sizes[l + 1][0] + sizes[l + 1][1]) * d * 4 if l < L else 0)
                         for l, (a, b) in enumerate(sizes) if l >= 1),
             "knob_scores0": (20000 + N) * row0,
             "knob_scoresN": sum((20000 + a) * d * 4 for l, (a, b) in enumerate(sizes) if l >= 1),

@@ -462,7 +462,8 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             for (int s = 0; s < 2; s++) {
                 if (l >= 1) {
                     Lv.npart[s] = P.lev[l - 1].nblk[s];
-                    OFF(Lv.P[s], (size_t)K[s] * Lv.n[s] * d * sizeof(float));
+                    // level 1 keeps only its normalised layer 0: its rows are re-formed from the inputs (k_pyramid MODE 2)
+                    OFF(Lv.P[s], (size_t)(l == 1 ? 1 : K[s]) * Lv.n[s] * d * sizeof(float));
                     OFF(Lv.part[s], (size_t)K[s] * Lv.npart[s] * d * sizeof(float));
                     OFF(Lv.mean[s], (size_t)K[s] * d * sizeof(float));
                 } else {

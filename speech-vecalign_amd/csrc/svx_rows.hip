@@ -91,10 +91,29 @@ struct Row {
 //   x = row - mean (if mean); den = ||x|| + 1e-5; vn = x / den            (make_norm1)
 //   nrm = 1 - <vn, rbar>                                                   (compute_norms)
 //   next[slot] = vn[2 slot] + vn[2 slot + 1]; part = column sums of next   (downsample_vectors)
+// Row r of level 1 straight from the level-0 rows: vn0[2r] + vn0[2r+1] with vn0 = row * 1/(||row|| + 1e-5) -- the
+// same two multiplications and one addition that the level-0 pass used to store (no contraction into an fma).
+template <typename E, int NCH>
+__device__ __forceinline__ void pair_row(const typename E::storage* rows0, const float* inv0, int r, int d, int lane, float* out) {
+#pragma clang fp contract(off)
+    using R = Row<E, NCH>;
+    float a[R::EPL], b[R::EPL];
+    R::load(rows0 + (size_t)(2 * r) * d, d, lane, a);
+    R::load(rows0 + (size_t)(2 * r + 1) * d, d, lane, b);
+    const float ia = inv0[2 * r], ib = inv0[2 * r + 1];
+#pragma unroll
+    for (int e = 0; e < R::EPL; e++) {
+        const float pa = a[e] * ia, pb = b[e] * ib;
+        out[e] = pa + pb;
+    }
+}
+
+// inv0 != null: `rows` are the level-0 rows and this block works on level 1, whose rows are formed on the fly
+// (pair_row) instead of being read back from memory.
 template <typename E, int NCH>
 __device__ void pyr_block(const typename E::storage* rows, int n, int d, const float* mean, const float* rbar,
                           float* inv_out, float* nrm_out, float* vn_out, float* next, float* part_out, int blk,
-                          float* lds) {
+                          float* lds, const float* inv0 = nullptr) {
     // lds: [2][NCH*VEC*64] floats for mean / rbar (zero padded), then [4][EPL][64] for the partials
     using R = Row<E, NCH>;
     constexpr int EPL = R::EPL;
@@ -117,14 +136,20 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
     r1 = r1 < n ? r1 : n;
     float xs[EPL];   // running pair sum
     float xn[EPL];   // the next row, in flight while the current one is processed
-    if (r0 < r1) R::load(rows + (size_t)r0 * d, d, lane, xn);
+    if (r0 < r1) {
+        if (inv0) pair_row<E, NCH>(rows, inv0, r0, d, lane, xn);
+        else R::load(rows + (size_t)r0 * d, d, lane, xn);
+    }
 #pragma unroll 1
     for (int r = r0; r < r1; r++) {
         const int jp = r >> 1, half = r & 1;
         float x[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; e++) x[e] = xn[e];
-        if (r + 1 < r1) R::load(rows + (size_t)(r + 1) * d, d, lane, xn);
+        if (r + 1 < r1) {
+            if (inv0) pair_row<E, NCH>(rows, inv0, r + 1, d, lane, xn);
+            else R::load(rows + (size_t)(r + 1) * d, d, lane, xn);
+        }
         if (mean) {
             float mu[EPL];
             R::loadf(mu_l, DP, lane, mu);
@@ -150,7 +175,7 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
         }
         if (lane == 0 && inv_out) inv_out[r] = rden;
         if (vn_out) R::storef(vn_out + (size_t)r * d, d, lane, x);
-        if (next) {
+        if (next || part_out) {  // (the level-0 pass keeps only the column sums: level 1 re-forms its rows)
             if (half == 0) {
 #pragma unroll
                 for (int e = 0; e < EPL; e++) xs[e] = x[e];
@@ -160,7 +185,7 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
                     xs[e] = xs[e] + x[e];
                     cs[e] += xs[e];
                 }
-                R::storef_nt(next + (size_t)jp * d, d, lane, xs);
+                if (next) R::storef_nt(next + (size_t)jp * d, d, lane, xs);
             }
         }
     }
@@ -186,7 +211,8 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
 // Mean of K*S sampled rows (optionally mean-subtracted and unit-normalised first).
 template <typename E, int NCH>
 __device__ void sample_mean_block(const typename E::storage* base, int K, int n, int d, const int* idx, int S,
-                                  const float* mean /*[K][d] or null*/, bool normalize, float* rbar, float* lds) {
+                                  const float* mean /*[K][d] or null*/, bool normalize, float* rbar, float* lds,
+                                  const float* inv0 = nullptr, int n0 = 0) {
     using R = Row<E, NCH>;
     constexpr int EPL = R::EPL;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -200,7 +226,8 @@ __device__ void sample_mean_block(const typename E::storage* base, int K, int n,
         int r = idx[i];
         r = r < 0 ? 0 : (r >= n ? n - 1 : r);  // indices are validated on the host; never fault
         float x[EPL];
-        R::load(base + ((size_t)k * n + r) * d, d, lane, x);
+        if (inv0) pair_row<E, NCH>(base + (size_t)k * n0 * d, inv0 + (size_t)k * n0, r, d, lane, x);
+        else R::load(base + ((size_t)k * n + r) * d, d, lane, x);
         if (mean) {
             float mu[EPL];
             R::loadf(mean + (size_t)k * d, d, lane, mu);
@@ -236,8 +263,11 @@ __device__ void sample_mean_block(const typename E::storage* base, int K, int n,
 }
 
 // ---------------------------------------------------------------- fused-pipeline kernels
-template <typename E, int NCH, bool LV0>
+// MODE 0: levels >= 2 (fp32 pair sums of the level above), 1: level 0 (the inputs), 2: level 1, rows formed from
+// the level-0 inputs and their 1/norm on the fly.
+template <typename E, int NCH, int MODE>
 __global__ __launch_bounds__(256) void k_pyramid(const SvxPairDev* __restrict__ pairs, int level) {
+    constexpr bool LV0 = MODE == 1;
     __shared__ float lds[6 * NCH * E::VEC * SVX_WAVE];
     const SvxPairDev& P = pairs[blockIdx.z];
     if (level > P.L) return;
@@ -254,8 +284,11 @@ __global__ __launch_bounds__(256) void k_pyramid(const SvxPairDev* __restrict__ 
     if ((int)blockIdx.x >= Lv.nblk[side]) return;
     const int n = Lv.n[side], d = P.d;
     using S = typename E::storage;
+    const int n0 = P.lev[0].n[side];
     const S* rows = LV0 ? reinterpret_cast<const S*>(P.v[side]) + (size_t)k * n * d
-                        : reinterpret_cast<const S*>(Lv.P[side] + (size_t)k * n * d);
+                        : (MODE == 2 ? reinterpret_cast<const S*>(P.v[side]) + (size_t)k * n0 * d
+                                     : reinterpret_cast<const S*>(Lv.P[side] + (size_t)k * n * d));
+    const float* inv0 = MODE == 2 ? P.lev[0].inv[side] + (size_t)k * n0 : nullptr;
     const float* mean = LV0 ? nullptr : Lv.mean[side] + (size_t)k * d;
     const bool want_nrm = !(LV0 && P.norm_override[side]);
     const float* rbar = want_nrm ? Lv.rbar[1 - side] : nullptr;
@@ -263,9 +296,9 @@ __global__ __launch_bounds__(256) void k_pyramid(const SvxPairDev* __restrict__ 
     float* nrm_out = want_nrm ? Lv.nrm[side] + (size_t)k * n : nullptr;
     float* vn_out = (!LV0 && k == 0) ? Lv.P[side] : nullptr;  // layer 0 is normalised in place
     const bool has_next = level < P.L;
-    float* next = has_next ? P.lev[level + 1].P[side] + (size_t)k * (n / 2) * d : nullptr;
+    float* next = (has_next && !LV0) ? P.lev[level + 1].P[side] + (size_t)k * (n / 2) * d : nullptr;
     float* part = has_next ? P.lev[level + 1].part[side] + ((size_t)k * Lv.nblk[side] + blockIdx.x) * d : nullptr;
-    pyr_block<E, NCH>(rows, n, d, mean, rbar, inv_out, nrm_out, vn_out, next, part, blockIdx.x, lds);
+    pyr_block<E, NCH>(rows, n, d, mean, rbar, inv_out, nrm_out, vn_out, next, part, blockIdx.x, lds, inv0);
 }
 
 __global__ __launch_bounds__(256) void k_colmean(const SvxPairDev* __restrict__ pairs, int level) {
@@ -290,8 +323,9 @@ __global__ __launch_bounds__(256) void k_colmean(const SvxPairDev* __restrict__ 
     Lv.mean[side][(size_t)k * P.d + c] = s / (float)Lv.n[side];
 }
 
-template <typename E, int NCH, bool LV0>
+template <typename E, int NCH, int MODE>
 __global__ __launch_bounds__(256) void k_sample_mean(const SvxPairDev* __restrict__ pairs, int level) {
+    constexpr bool LV0 = MODE == 1;
     __shared__ float lds[4 * NCH * E::VEC * SVX_WAVE];
     const SvxPairDev& P = pairs[blockIdx.y];
     if (level > P.L) return;
@@ -299,9 +333,9 @@ __global__ __launch_bounds__(256) void k_sample_mean(const SvxPairDev* __restric
     const SvxLevel& Lv = P.lev[level];
     if (Lv.S[side] <= 0 || Lv.sidx[side] == nullptr) return;
     using S = typename E::storage;
-    const S* base = LV0 ? reinterpret_cast<const S*>(P.v[side]) : reinterpret_cast<const S*>(Lv.P[side]);
+    const S* base = (LV0 || MODE == 2) ? reinterpret_cast<const S*>(P.v[side]) : reinterpret_cast<const S*>(Lv.P[side]);
     sample_mean_block<E, NCH>(base, P.K[side], Lv.n[side], P.d, Lv.sidx[side], Lv.S[side], LV0 ? nullptr : Lv.mean[side],
-                              true, Lv.rbar[side], lds);
+                              true, Lv.rbar[side], lds, MODE == 2 ? P.lev[0].inv[side] : nullptr, P.lev[0].n[side]);
 }
 
 // ---------------------------------------------------------------- per-op (plain pointer) kernels
@@ -518,25 +552,26 @@ int svxl_pyramid_level(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int l
         hipLaunchKernelGGL(k_colmean, dim3((d + 255) / 256, max_ksum, n_pairs), dim3(256), 0, st, pairs, level);
         SVX_LAUNCH_CHECK(ctx, "k_colmean");
     }
-#define LAUNCH(E, N, LV0)                                                                                              \
+#define LAUNCH(E, N, MODE)                                                                                             \
     do {                                                                                                               \
-        if (part == 0) hipLaunchKernelGGL((k_sample_mean<E, N, LV0>), dim3(2, n_pairs), dim3(256), 0, st, pairs, level); \
-        else hipLaunchKernelGGL((k_pyramid<E, N, LV0>), dim3(max_nblk, max_ksum, n_pairs), dim3(256), 0, st, pairs, level); \
+        if (part == 0) hipLaunchKernelGGL((k_sample_mean<E, N, MODE>), dim3(2, n_pairs), dim3(256), 0, st, pairs, level); \
+        else hipLaunchKernelGGL((k_pyramid<E, N, MODE>), dim3(max_nblk, max_ksum, n_pairs), dim3(256), 0, st, pairs, level); \
     } while (0)
-    if (level >= 1) {
-#define M(N) LAUNCH(ElemF32, N, false)
+    const int mode = level == 0 ? 1 : (level == 1 ? 2 : 0);
+    if (mode == 0) {
+#define M(N) LAUNCH(ElemF32, N, 0)
         SVX_SWITCH_NCH_F32(d, M)
 #undef M
     } else if (dtype == SVX_F32) {
-#define M(N) LAUNCH(ElemF32, N, true)
+#define M(N) do { if (mode == 1) LAUNCH(ElemF32, N, 1); else LAUNCH(ElemF32, N, 2); } while (0)
         SVX_SWITCH_NCH_F32(d, M)
 #undef M
     } else if (dtype == SVX_F16) {
-#define M(N) LAUNCH(ElemF16, N, true)
+#define M(N) do { if (mode == 1) LAUNCH(ElemF16, N, 1); else LAUNCH(ElemF16, N, 2); } while (0)
         SVX_SWITCH_NCH_16(d, M)
 #undef M
     } else {
-#define M(N) LAUNCH(ElemBF16, N, true)
+#define M(N) do { if (mode == 1) LAUNCH(ElemBF16, N, 1); else LAUNCH(ElemBF16, N, 2); } while (0)
         SVX_SWITCH_NCH_16(d, M)
 #undef M
     }
