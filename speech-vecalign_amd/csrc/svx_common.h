@@ -63,14 +63,37 @@ __device__ __forceinline__ void load_piece<ElemBF16>(const uint16_t* p, float* o
     }
 }
 
+// Exchange with lane ^ 16 / lane ^ 32 through the gfx950 permlane swaps (VALU, no LDS round trip).
+__device__ __forceinline__ unsigned xchg16_u32(unsigned v, int lane) {
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return ((lane >> 4) & 1) ? r[0] : r[1];
+}
+__device__ __forceinline__ unsigned xchg32_u32(unsigned v, int lane) {
+    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (lane & 32) ? r[0] : r[1];
+}
+#define SVX_DPP_F32(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
+
+// Wave-wide reductions on the VALU only: two quad permutes, the half-row and row mirrors (after which all 16
+// lanes of a row agree), then the two permlane swaps across rows.  Every lane ends with the result.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 1; m < SVX_WAVE; m <<= 1) v += __shfl_xor(v, m, SVX_WAVE);
+    const int lane = threadIdx.x & 63;
+    v += SVX_DPP_F32(v, 0xB1);   // quad_perm [1,0,3,2]
+    v += SVX_DPP_F32(v, 0x4E);   // quad_perm [2,3,0,1]
+    v += SVX_DPP_F32(v, 0x141);  // row_half_mirror
+    v += SVX_DPP_F32(v, 0x140);  // row_mirror
+    v += __uint_as_float(xchg16_u32(__float_as_uint(v), lane));
+    v += __uint_as_float(xchg32_u32(__float_as_uint(v), lane));
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int m = 1; m < SVX_WAVE; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, SVX_WAVE));
+    const int lane = threadIdx.x & 63;
+    v = fmaxf(v, SVX_DPP_F32(v, 0xB1));
+    v = fmaxf(v, SVX_DPP_F32(v, 0x4E));
+    v = fmaxf(v, SVX_DPP_F32(v, 0x141));
+    v = fmaxf(v, SVX_DPP_F32(v, 0x140));
+    v = fmaxf(v, __uint_as_float(xchg16_u32(__float_as_uint(v), lane)));
+    v = fmaxf(v, __uint_as_float(xchg32_u32(__float_as_uint(v), lane)));
     return v;
 }
 

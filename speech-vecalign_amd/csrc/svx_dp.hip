@@ -333,15 +333,6 @@ __device__ __forceinline__ void dpf_stage(const SparseDpArgs& g, const int* tpk,
     }
 }
 
-// Exchange with lane ^ 16 / lane ^ 32 through the gfx950 permlane swaps (VALU, no LDS round trip).
-__device__ __forceinline__ unsigned xchg16_u32(unsigned v, int lane) {
-    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    return ((lane >> 4) & 1) ? r[0] : r[1];
-}
-__device__ __forceinline__ unsigned xchg32_u32(unsigned v, int lane) {
-    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return (lane & 32) ? r[0] : r[1];
-}
 __device__ __forceinline__ double xchg16_f64(double v, int lane) {
     const unsigned long long u = __double_as_longlong(v);
     const unsigned lo = xchg16_u32((unsigned)u, lane), hi = xchg16_u32((unsigned)(u >> 32), lane);
