@@ -108,9 +108,66 @@ __device__ __forceinline__ void pair_row(const typename E::storage* rows0, const
     }
 }
 
-// inv0 != null: `rows` are the level-0 rows and this block works on level 1, whose rows are formed on the fly
-// (pair_row) instead of being read back from memory.
-template <typename E, int NCH>
+// A logical row as it comes out of memory: raw 16-byte pieces (converted when the row is used, so that several
+// rows can be in flight in few registers).  PAIR: the row is the sum of two scaled level-0 rows (pair_row).
+template <typename E, int NCH, bool PAIR>
+struct RawRow {
+    uint4 p[PAIR ? 2 * NCH : NCH];
+    float ia, ib;
+};
+
+template <typename E, int NCH, bool PAIR>
+__device__ __forceinline__ void fetch_raw(const typename E::storage* rows, const float* inv0, int r, int d, int lane,
+                                          RawRow<E, NCH, PAIR>& out) {
+    constexpr int VEC = E::VEC;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int col = (c * SVX_WAVE + lane) * VEC;
+        const bool in = col < d;
+        if (PAIR) {
+            out.p[c] = in ? *reinterpret_cast<const uint4*>(rows + (size_t)(2 * r) * d + col) : make_uint4(0, 0, 0, 0);
+            out.p[NCH + c] = in ? *reinterpret_cast<const uint4*>(rows + (size_t)(2 * r + 1) * d + col) : make_uint4(0, 0, 0, 0);
+        } else {
+            out.p[c] = in ? *reinterpret_cast<const uint4*>(rows + (size_t)r * d + col) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    if (PAIR) {
+        out.ia = inv0[2 * r];
+        out.ib = inv0[2 * r + 1];
+    }
+}
+
+template <typename E, int NCH, bool PAIR>
+__device__ __forceinline__ void decode_raw(const RawRow<E, NCH, PAIR>& in, float* x) {
+#pragma clang fp contract(off)
+    using S = typename E::storage;
+    constexpr int VEC = E::VEC;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        S tmp[VEC];
+        __builtin_memcpy(tmp, &in.p[c], 16);
+        float a[VEC];
+        load_piece<E>(tmp, a);
+        if (PAIR) {
+            S tmp2[VEC];
+            __builtin_memcpy(tmp2, &in.p[NCH + c], 16);
+            float b[VEC];
+            load_piece<E>(tmp2, b);
+#pragma unroll
+            for (int i = 0; i < VEC; i++) {
+                const float pa = a[i] * in.ia, pb = b[i] * in.ib;  // the two products and the sum of pair_row
+                x[c * VEC + i] = pa + pb;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; i++) x[c * VEC + i] = a[i];
+        }
+    }
+}
+
+// PAIR: `rows` are the level-0 rows and this block works on level 1, whose rows are formed on the fly
+// (pair_row arithmetic) instead of being read back from memory.
+template <typename E, int NCH, bool PAIR = false>
 __device__ void pyr_block(const typename E::storage* rows, int n, int d, const float* mean, const float* rbar,
                           float* inv_out, float* nrm_out, float* vn_out, float* next, float* part_out, int blk,
                           float* lds, const float* inv0 = nullptr) {
@@ -118,6 +175,7 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
     using R = Row<E, NCH>;
     constexpr int EPL = R::EPL;
     constexpr int DP = EPL * SVX_WAVE;  // padded row length
+    constexpr int DEPTH = PAIR ? 2 : (E::VEC == 8 ? 3 : 1);  // rows in flight per wave beyond the one being processed
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float* mu_l = lds;
     float* rb_l = lds + DP;
@@ -135,57 +193,57 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
     int r1 = r0 + 2 * (SVX_PYR_SLOTS / 4);   // this wave's rows: [r0, r1)
     r1 = r1 < n ? r1 : n;
     float xs[EPL];   // running pair sum
-    float xn[EPL];   // the next row, in flight while the current one is processed
-    if (r0 < r1) {
-        if (inv0) pair_row<E, NCH>(rows, inv0, r0, d, lane, xn);
-        else R::load(rows + (size_t)r0 * d, d, lane, xn);
-    }
+    RawRow<E, NCH, PAIR> ring[DEPTH];
+#pragma unroll
+    for (int s = 0; s < DEPTH; s++)
+        if (r0 + s < r1) fetch_raw<E, NCH, PAIR>(rows, inv0, r0 + s, d, lane, ring[s]);
 #pragma unroll 1
-    for (int r = r0; r < r1; r++) {
-        const int jp = r >> 1, half = r & 1;
-        float x[EPL];
+    for (int rb = r0; rb < r1; rb += DEPTH) {
 #pragma unroll
-        for (int e = 0; e < EPL; e++) x[e] = xn[e];
-        if (r + 1 < r1) {
-            if (inv0) pair_row<E, NCH>(rows, inv0, r + 1, d, lane, xn);
-            else R::load(rows + (size_t)(r + 1) * d, d, lane, xn);
-        }
-        if (mean) {
-            float mu[EPL];
-            R::loadf(mu_l, DP, lane, mu);
+        for (int s = 0; s < DEPTH; s++) {
+            const int r = rb + s;
+            if (r >= r1) break;  // wave-uniform
+            const int jp = r >> 1, half = r & 1;
+            float x[EPL];
+            decode_raw<E, NCH, PAIR>(ring[s], x);
+            if (r + DEPTH < r1) fetch_raw<E, NCH, PAIR>(rows, inv0, r + DEPTH, d, lane, ring[s]);
+            if (mean) {
+                float mu[EPL];
+                R::loadf(mu_l, DP, lane, mu);
 #pragma unroll
-            for (int e = 0; e < EPL; e++) x[e] = x[e] - mu[e];  // columns >= d: 0 - 0
-        }
-        float ss = 0.f;
+                for (int e = 0; e < EPL; e++) x[e] = x[e] - mu[e];  // columns >= d: 0 - 0
+            }
+            float ss = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPL; e++) ss += x[e] * x[e];
-        ss = wave_sum(ss);
-        const float den = sqrtf(ss) + 1e-5f;
-        const float rden = 1.0f / den;  // one division per row; the elements are scaled by the reciprocal
+            for (int e = 0; e < EPL; e++) ss += x[e] * x[e];
+            ss = wave_sum(ss);
+            const float den = sqrtf(ss) + 1e-5f;
+            const float rden = 1.0f / den;  // one division per row; the elements are scaled by the reciprocal
 #pragma unroll
-        for (int e = 0; e < EPL; e++) x[e] = x[e] * rden;
-        if (rbar) {
-            float rb[EPL];
-            R::loadf(rb_l, DP, lane, rb);
-            float dt = 0.f;
+            for (int e = 0; e < EPL; e++) x[e] = x[e] * rden;
+            if (rbar) {
+                float rbv[EPL];
+                R::loadf(rb_l, DP, lane, rbv);
+                float dt = 0.f;
 #pragma unroll
-            for (int e = 0; e < EPL; e++) dt += x[e] * rb[e];
-            dt = wave_sum(dt);
-            if (lane == 0 && nrm_out) nrm_out[r] = 1.0f - dt;
-        }
-        if (lane == 0 && inv_out) inv_out[r] = rden;
-        if (vn_out) R::storef(vn_out + (size_t)r * d, d, lane, x);
-        if (next || part_out) {  // (the level-0 pass keeps only the column sums: level 1 re-forms its rows)
-            if (half == 0) {
+                for (int e = 0; e < EPL; e++) dt += x[e] * rbv[e];
+                dt = wave_sum(dt);
+                if (lane == 0 && nrm_out) nrm_out[r] = 1.0f - dt;
+            }
+            if (lane == 0 && inv_out) inv_out[r] = rden;
+            if (vn_out) R::storef(vn_out + (size_t)r * d, d, lane, x);
+            if (next || part_out) {  // (the level-0 pass keeps only the column sums: level 1 re-forms its rows)
+                if (half == 0) {
 #pragma unroll
-                for (int e = 0; e < EPL; e++) xs[e] = x[e];
-            } else {
+                    for (int e = 0; e < EPL; e++) xs[e] = x[e];
+                } else {
 #pragma unroll
-                for (int e = 0; e < EPL; e++) {
-                    xs[e] = xs[e] + x[e];
-                    cs[e] += xs[e];
+                    for (int e = 0; e < EPL; e++) {
+                        xs[e] = xs[e] + x[e];
+                        cs[e] += xs[e];
+                    }
+                    if (next) R::storef_nt(next + (size_t)jp * d, d, lane, xs);
                 }
-                if (next) R::storef_nt(next + (size_t)jp * d, d, lane, xs);
             }
         }
     }
@@ -298,7 +356,7 @@ __global__ __launch_bounds__(256) void k_pyramid(const SvxPairDev* __restrict__ 
     const bool has_next = level < P.L;
     float* next = (has_next && !LV0) ? P.lev[level + 1].P[side] + (size_t)k * (n / 2) * d : nullptr;
     float* part = has_next ? P.lev[level + 1].part[side] + ((size_t)k * Lv.nblk[side] + blockIdx.x) * d : nullptr;
-    pyr_block<E, NCH>(rows, n, d, mean, rbar, inv_out, nrm_out, vn_out, next, part, blockIdx.x, lds, inv0);
+    pyr_block<E, NCH, MODE == 2>(rows, n, d, mean, rbar, inv_out, nrm_out, vn_out, next, part, blockIdx.x, lds, inv0);
 }
 
 __global__ __launch_bounds__(256) void k_colmean(const SvxPairDev* __restrict__ pairs, int level) {
