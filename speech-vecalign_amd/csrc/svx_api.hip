@@ -481,6 +481,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             if (Lv.kn > max_kn) max_kn = Lv.kn;
             OFF(Lv.kscore, (size_t)kn * sizeof(float));
             OFF(Lv.korder, (size_t)kn * sizeof(int));
+            OFF(Lv.kys, (size_t)kn * sizeof(int));
             OFF(Lv.kstart, (size_t)(Lv.n[0] + 1) * sizeof(int));
             if (in.del_pen) Lv.pen = in.del_pen + l;
             else OFF(Lv.pen, sizeof(double));
@@ -540,7 +541,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
                 patch(Lv.P[s]); patch(Lv.part[s]); patch(Lv.mean[s]); patch(Lv.rbar[s]); patch(Lv.inv[s]);
                 if (!(l == 0 && P.norm_override[s])) patch(Lv.nrm[s]);
             }
-            patch(Lv.kscore); patch(Lv.korder); patch(Lv.kstart);
+            patch(Lv.kscore); patch(Lv.korder); patch(Lv.kys); patch(Lv.kstart);
             if (!in.del_pen) patch(Lv.pen);
             patch(Lv.path); patch(Lv.path_len); patch(Lv.costs); patch(Lv.boff); patch(Lv.csum); patch(Lv.xp); patch(Lv.yp); patch(Lv.bpk);
             patch(Lv.boff_out);

@@ -116,6 +116,7 @@ struct SvxLevel {
     int path_cap;
     float* kscore;     // [kn]
     int* korder;       // [kn] sample ids grouped by source row
+    int* kys;          // [kn] target row of korder[pos] (clamped), so that the scoring pass needs no dependent lookups
     int* kstart;       // [n0 + 1] first position of each source row in korder
     double* pen;       // deletion penalty of this level
     int* path;         // [path_cap][2]

@@ -274,7 +274,12 @@ __global__ __launch_bounds__(256) void k_knob_sort(const SvxPairDev* __restrict_
     for (int i = tid; i < kn; i += 256) {
         int x = Lv.kx[i];
         x = x < 0 ? 0 : (x >= n ? n - 1 : x);
-        Lv.korder[atomicAdd(&cnt[x], 1)] = i;
+        const int pos = atomicAdd(&cnt[x], 1);
+        const int m = Lv.n[1];
+        int y = Lv.ky[i];
+        y = y < 0 ? 0 : (y >= m ? m - 1 : y);
+        Lv.korder[pos] = i;
+        Lv.kys[pos] = y;
     }
 }
 
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restric
     if (!LV0 && level == P.L) return;  // the coarsest level's samples read the dense stage's dots (k_knob_from_dots)
     const SvxLevel& Lv = P.lev[level];
     const int lane = threadIdx.x & 63;
-    const int n = Lv.n[0], m = Lv.n[1], d = P.d;
+    const int n = Lv.n[0], d = P.d;
     const S* v1 = LV0 ? reinterpret_cast<const S*>(P.v[0]) : reinterpret_cast<const S*>(Lv.P[0]);
     const S* v2 = LV0 ? reinterpret_cast<const S*>(P.v[1]) : reinterpret_cast<const S*>(Lv.P[1]);
     const float* inv1 = LV0 ? Lv.inv[0] : nullptr;
@@ -315,19 +320,34 @@ __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restric
         }
         const float nx = Lv.nrm[0][x];
         const float ix = LV0 ? inv1[x] : 1.0f;
+        // sample ids / target rows are read one sample ahead, the target row itself is in flight while the
+        // previous dot product is reduced: one memory round trip per sample instead of three
+        int i_cur = Lv.korder[s0], y_cur = Lv.kys[s0];
+        uint4 yraw[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int col = (c * SVX_WAVE + lane) * E::VEC;
+            yraw[c] = col < d ? *reinterpret_cast<const uint4*>(v2 + (size_t)y_cur * d + col) : make_uint4(0, 0, 0, 0);
+        }
         for (int s = s0; s < s1; s++) {
-            const int i = Lv.korder[s];
-            int y = Lv.ky[i];
-            y = y < 0 ? 0 : (y >= m ? m - 1 : y);
+            const int i = i_cur, y = y_cur;
+            const bool more = s + 1 < s1;
+            if (more) { i_cur = Lv.korder[s + 1]; y_cur = Lv.kys[s + 1]; }
             float dot = 0.f;
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
-                const int col = (c * SVX_WAVE + lane) * E::VEC;
-                if (col < d) {
-                    float yr[E::VEC];
-                    load_piece<E>(v2 + (size_t)y * d + col, yr);
+                S tmp[E::VEC];
+                __builtin_memcpy(tmp, &yraw[c], 16);
+                float yr[E::VEC];
+                load_piece<E>(tmp, yr);
 #pragma unroll
-                    for (int k = 0; k < E::VEC; k++) dot += xr[c * E::VEC + k] * yr[k];
+                for (int k = 0; k < E::VEC; k++) dot += xr[c * E::VEC + k] * yr[k];
+            }
+            if (more) {
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    const int col = (c * SVX_WAVE + lane) * E::VEC;
+                    yraw[c] = col < d ? *reinterpret_cast<const uint4*>(v2 + (size_t)y_cur * d + col) : make_uint4(0, 0, 0, 0);
                 }
             }
             dot = wave_sum(dot);
