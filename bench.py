@@ -114,7 +114,7 @@ def main():
     first = pb.results() if args.warmup > 0 else None
     if not args.no_profile:
         lib.svx_set_profiling(ctx.h, 1)
-    stage_names = ["pyr0", "pyrN", "pyr_aux", "knob_sort", "knob_scores0", "knob_scoresN", "knob", "dense_costs", "dense_dp",
+    stage_names = ["pyr0", "pyr1", "pyrN", "pyr_aux", "knob_sort", "knob_scores0", "knob_scoresN", "knob", "dense_costs", "dense_dp",
                    "path", "band_costs0", "band_costsN", "band_dp0", "band_dpN", "traceback", "setup", "total", "host_plan",
                    "host_launch"]
     stage_ms = {s: 0.0 for s in stage_names}
@@ -170,11 +170,12 @@ def main():
         alg = {
             # level 0 only reads the inputs (norms, column sums); level 1 re-reads them and forms its rows on the fly
             "pyr0": K * (N + M) * row0,
-            "pyrN": sum((K * (N + M) * row0 if l == 1 else K * (a + b) * d * 4) + (a + b) * d * 4 +
-                        (K * (sizes[l + 1][0] + sizes[l + 1][1]) * d * 4 if l < L else 0)
-                        for l, (a, b) in enumerate(sizes) if l >= 1),
+            "pyr1": (K * (N + M) * row0 + (sizes[1][0] + sizes[1][1]) * d * 4 +
+                     (K * (sizes[2][0] + sizes[2][1]) * d * 4 if L >= 2 else 0)) if L >= 1 else 0,
+            "pyrN": sum(K * (a + b) * d * 4 + (a + b) * d * 4 + (K * (sizes[l + 1][0] + sizes[l + 1][1]) * d * 4 if l < L else 0)
+                        for l, (a, b) in enumerate(sizes) if l >= 2),
             "knob_scores0": (20000 + N) * row0,
-            "knob_scoresN": sum((20000 + a) * d * 4 for l, (a, b) in enumerate(sizes) if l >= 1),
+            "knob_scoresN": sum((20000 + a) * d * 4 for l, (a, b) in enumerate(sizes) if 1 <= l < L),
             "band_costs0": K * (N + M) * row0 + T * (N + M + 3) * Bw * 4,
             "band_costsN": sum((a + b) * d * 4 + (a + b + 3) * Bw * 4 for l, (a, b) in enumerate(sizes) if 1 <= l < L),
             "band_dp0": (T * 4 + 9) * (N + M + 5) * Bw,
@@ -182,31 +183,35 @@ def main():
         }
         alg_bytes_pair = K * (N + M) * row0
         if not args.no_profile and stage_ms["total"] > 0:
-            kernels = {k: v for k, v in stage_ms.items() if k in alg}
-            dom = max(kernels, key=kernels.get)
-            launches = max(1, stage_launch[dom])
-            avg_ms = kernels[dom] / launches
-            per_launch_bytes = alg[dom] * P * args.steps / launches
+            # stages that are launches of the same kernel (template) are one entry; the dominant KERNEL is the
+            # entry with the largest share of the step
+            groups = {"k_pyramid": ["pyr0", "pyr1", "pyrN"], "k_band_costs_batch": ["band_costs0", "band_costsN"],
+                      "k_knob_scores": ["knob_scores0", "knob_scoresN"], "k_sparse_dp_fast_batch": ["band_dp0", "band_dpN"]}
+            gms = {g: sum(stage_ms[k] for k in ks) for g, ks in groups.items()}
+            dom = max(gms, key=gms.get)
+            launches = max(1, sum(stage_launch[k] for k in groups[dom]))
+            avg_ms = gms[dom] / launches
+            per_launch_bytes = sum(alg[k] for k in groups[dom]) * P * args.steps / launches
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
             # HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of
-            # MI355X_MICROARCH.md), measured separately per pair and scaled to this launch: profiles/r01_hbm_traffic.json
+            # MI355X_MICROARCH.md), measured per pair and per launch of every instantiation (profiles/r01_hbm_traffic.json),
+            # weighted by the launches each instantiation has in a step and averaged like avg_ms
             traffic = None
             try:
-                import re
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))["hbm_bytes_per_pair_per_launch"]
-                pat = {"pyr0": r"k_pyramid<.*true>", "pyrN": r"k_pyramid<ElemF32, \d+, false>", "knob_scores0": r"k_knob_scores<.*true>",
-                       "knob_scoresN": r"k_knob_scores<ElemF32, \d+, false>", "band_costs0": r"k_band_costs_batch<.*true",
-                       "band_costsN": r"k_band_costs_batch<ElemF32, false", "band_dp0": r"k_sparse_dp_fast_batch<3, 4>",
-                       "band_dpN": r"k_sparse_dp_fast_batch<1, 1>"}[dom]
-                hit = [v for k, v in tj.items() if re.match(pat, k)]
-                if hit and args.dtype == "bf16" and (N, M, K, d) == (4096, 4096, 4, 1024):
-                    traffic = hit[0] * P
+                if args.dtype == "bf16" and (N, M, K, d) == (4096, 4096, 4, 1024):
+                    per_step = {"k_pyramid": [("k_pyramid<ElemBF16, 2, 1>", 1), ("k_pyramid<ElemBF16, 2, 2>", 1), ("k_pyramid<ElemF32, 4, 0>", L - 1)],
+                                "k_band_costs_batch": [("k_band_costs_batch<ElemBF16, true, 12, 2>", 1), ("k_band_costs_batch<ElemF32, false, 6, 4>", L - 1)],
+                                "k_knob_scores": [("k_knob_scores<ElemBF16, 2, true>", 1), ("k_knob_scores<ElemF32, 4, false>", 1)],
+                                "k_sparse_dp_fast_batch": [("k_sparse_dp_fast_batch<3, 4>", 1), ("k_sparse_dp_fast_batch<1, 1>", L - 1)]}[dom]
+                    traffic = sum(tj[k] * c for k, c in per_step) * P / sum(c for _, c in per_step)
             except Exception:
                 traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "stages": groups[dom], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                                "frac": achieved / 8000.0, "traffic": traffic,
                                "avg_launch_ms": avg_ms, "launches": launches,
                                "algorithmic_bytes_per_launch": per_launch_bytes,
+                               "share_of_step": gms[dom] / stage_ms["total"],
                                "whole_path_input_bytes_per_pair": alg_bytes_pair,
                                "whole_path_GBps": alg_bytes_pair * value / max(1, world) / 1e9}
             out["stage_ms_per_step"] = {k: v / args.steps for k, v in stage_ms.items()}

@@ -200,7 +200,7 @@ int svx_align_batch(svx_ctx *ctx, const svx_align_params *params, const svx_pair
 
 /* Device time of the named stage of the last svx_align_batch call, in milliseconds, measured with
  * HIP events on the context's stream when profiling is on (svx_set_profiling); one name per kernel:
- * "pyr0" "pyrN" "pyr_aux" "knob_sort" "knob_scores0" "knob_scoresN" "knob" "dense_costs" "dense_dp" "path"
+ * "pyr0" "pyr1" "pyrN" "pyr_aux" "knob_sort" "knob_scores0" "knob_scoresN" "knob" "dense_costs" "dense_dp" "path"
  * "band_costs0" "band_costsN" "band_dp0" "band_dpN" "traceback" "setup" "total" (0 = level 0, N = deeper levels);
  * "host_plan"/"host_launch" are host wall-clock.  -1 if unknown. */
 int svx_set_profiling(svx_ctx *ctx, int on);

@@ -23,10 +23,10 @@ int svx_fail(svx_ctx* ctx, int code, const char* fmt, ...) {
 
 static const char* kStageNames[] = {"pyr0",       "pyrN",     "pyr_aux",      "knob_scoresN", "knob",      "dense_costs",
                                     "dense_dp",   "path",     "band_costs0",  "band_costsN",  "band_dp0",  "band_dpN",
-                                    "traceback",  "setup",    "total",        "host_plan",    "host_launch", "knob_sort", "knob_scores0"};
+                                    "traceback",  "setup",    "total",        "host_plan",    "host_launch", "knob_sort", "knob_scores0", "pyr1"};
 enum {
     S_PYR0 = 0, S_PYRN, S_PYR_AUX, S_KNOB_SCORES, S_KNOB, S_DENSE_COSTS, S_DENSE_DP, S_PATH, S_BAND_COSTS0, S_BAND_COSTSN,
-    S_BAND_DP0, S_BAND_DPN, S_TRACEBACK, S_SETUP, S_TOTAL, S_HOST_PLAN, S_HOST_LAUNCH, S_KNOB_SORT, S_KNOB_SCORES0, S_COUNT
+    S_BAND_DP0, S_BAND_DPN, S_TRACEBACK, S_SETUP, S_TOTAL, S_HOST_PLAN, S_HOST_LAUNCH, S_KNOB_SORT, S_KNOB_SCORES0, S_PYR1, S_COUNT
 };
 
 struct StageRec {
@@ -567,7 +567,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
                 StageScope sc(ctx, S_PYR_AUX);
                 if ((rc2 = svxl_pyramid_level(ctx, dp, np, l, dtype, d, max_nblk[l], max_ksum, 0))) return rc2;
             }
-            StageScope sc(ctx, l == 0 ? S_PYR0 : S_PYRN);
+            StageScope sc(ctx, l == 0 ? S_PYR0 : (l == 1 ? S_PYR1 : S_PYRN));
             if ((rc2 = svxl_pyramid_level(ctx, dp, np, l, dtype, d, max_nblk[l], max_ksum, 1))) return rc2;
         }
         {
