@@ -154,6 +154,8 @@ def main():
                                (N, M, d, args.dtype, K, len(types), 2 * W, P),
                    "pairs_per_step_per_gpu": P, "streams": args.streams, "N": N, "M": M, "d": d, "overlaps": K, "parallelism": "dp%d (pairs sharded, no collective)" % world},
         "dp_cells_per_s": value * cells, "dp_cells_per_pair": cells,
+        "hbm_bytes_resident": {"inputs": int(sum(a.numel() * a.element_size() + b.numel() * b.element_size() for a, b in docs)),
+                               "scratch_arena": int(lib.svx_scratch_bytes(ctx.h))},
     }
 
     if rank == 0:

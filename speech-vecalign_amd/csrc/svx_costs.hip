@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256) void k_knob_sort(const SvxPairDev* __restrict_
     const SvxPairDev& P = pairs[blockIdx.y];
     const int level = blockIdx.x;
     if (level > P.L) return;
+    if (P.L >= 1 && level == P.L) return;  // the coarsest level's samples are scored unsorted (k_knob_from_dots)
     const SvxLevel& Lv = P.lev[level];
     const int n = Lv.n[0], kn = Lv.kn, tid = threadIdx.x;
     int* cnt = reinterpret_cast<int*>(smem);  // [n]
