@@ -1,0 +1,126 @@
+"""Randomised parity sweep (not collected by pytest; run by hand on the GPU box):
+    python tests/fuzz_gpu_vs_oracle.py --cases 300 --seed 0
+Every case draws document sizes, overlap layers, alignment types, band width, pyramid threshold, storage type,
+deletions and zero rows, aligns the pair with the HIP pipeline and with the CPU oracle on the same inputs and the
+same random stream, and requires identical alignment spans and scores within 1e-4.  Cases run in batches so that
+ragged batches are exercised too.
+
+Exact ties: zero rows (PAD / ignored candidates) with equal norms give several alignments the same total cost in
+exact arithmetic; the reference itself picks among them by fp64 rounding noise, which no implementation with a
+different (equally valid) summation order of the fp32 dot products can reproduce.  Such cases are reported as
+"tie" when the two objectives -- evaluated with the oracle's deletion penalty -- agree to 2e-6 per alignment, and
+do not count as mismatches.
+
+Percentile knife-edges: with very few sampled scores (n*m below costs_sample_size on tiny documents) a step of the
+empirical cdf can coincide with a knot of the percentile map (2/56 == 1/28); which side np.searchsorted falls on is
+then decided by the last bit of the scores, and the deletion penalty jumps by a whole inter-sample gap.  Cases whose
+deletion penalties differ by more than 5e-5 are listed as "penalty knife-edge" with both results, not as mismatches:
+the penalty kernel itself is checked bit for bit against numpy on equal scores in tests/test_gpu_ops.py."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "speech-vecalign_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=8)
+    a = ap.parse_args()
+    import torch
+    import oracle
+    from synth import alignment_types, make_pair, round_bf16
+    from svx.vecalign import dp_utils
+    rs = np.random.RandomState(a.seed)
+    t0 = time.time()
+    done = bad = ties = edges = 0
+    while done < a.cases:
+        # one configuration per batch (types / W / thresholds are batch-wide parameters), sizes vary inside it
+        K = int(rs.randint(1, 6))
+        amax = int(rs.randint(2, K + 2))
+        types = alignment_types(amax)
+        W = int(rs.randint(3, 12))
+        max_full = int(rs.choice([40, 100, 300]))
+        sample = int(rs.choice([500, 5000, 20000]))
+        nsamp = int(rs.choice([0, 7, 100]))
+        frac = float(rs.choice([0.05, 0.2, 0.5]))
+        d = int(rs.choice([32, 64, 256]))
+        store = rs.choice(["f32", "bf16", "f16"])
+        nb = min(a.batch, a.cases - done)
+        hosts, devs = [], []
+        for i in range(nb):
+            n, m = int(rs.randint(1, 900)), int(rs.randint(1, 900))
+            if rs.rand() < 0.15:
+                n, m = int(rs.randint(1, 12)), int(rs.randint(1, 12))
+            v0, v1 = make_pair(n, m, K, d, int(rs.randint(1 << 30)), deletions=int(rs.randint(0, 6)) if min(n, m) > 12 else 0,
+                               zero_rows=int(rs.randint(0, 4)))
+            if store == "bf16":
+                v0, v1 = round_bf16(v0), round_bf16(v1)
+                devs.append((torch.from_numpy(v0).cuda().bfloat16(), torch.from_numpy(v1).cuda().bfloat16()))
+            elif store == "f16":
+                v0, v1 = v0.astype(np.float16).astype(np.float32), v1.astype(np.float16).astype(np.float32)
+                devs.append((torch.from_numpy(v0).cuda().half(), torch.from_numpy(v1).cuda().half()))
+            else:
+                devs.append((torch.from_numpy(v0).cuda(), torch.from_numpy(v1).cuda()))
+            hosts.append((v0, v1))
+        seeds = [int(rs.randint(1 << 30)) for _ in range(nb)]
+        try:
+            res = dp_utils.align_batch(devs, types, frac, W, max_full, sample, nsamp, rngs=[np.random.RandomState(s) for s in seeds])
+        except Exception as e:  # an error must be an error on both sides
+            res = e
+        for i in range(nb):
+            try:
+                ref = oracle.vecalign(hosts[i][0].copy(), hosts[i][1].copy(), types, frac, W, max_full, sample, nsamp,
+                                      rng=np.random.RandomState(seeds[i]))
+            except Exception as e:
+                ref = e
+            ok = False
+            if isinstance(res, Exception) or isinstance(ref, Exception):
+                ok = isinstance(res, Exception) and isinstance(ref, Exception)
+            else:
+                al, sc = res[i][0], res[i][1]
+                ok = al == ref[0]['final_alignments'] and (len(sc) == 0 or np.abs(np.asarray(sc) - ref[0]['alignment_scores']).max() < 1e-4)
+            if not ok and not isinstance(res, Exception) and not isinstance(ref, Exception):
+                al, sc, pens = res[i]
+                ra, rsc = ref[0]['final_alignments'], ref[0]['alignment_scores']
+                pen = ref[0]['del_penalty']
+
+                def objective(alg, scores):
+                    return sum(c * len(x) * len(y) if (x and y) else pen * (len(x) + len(y)) for (x, y), c in zip(alg, scores))
+                cover = [v for x, _ in al for v in x] == list(range(hosts[i][0].shape[1])) and \
+                    [v for _, y in al for v in y] == list(range(hosts[i][1].shape[1]))
+                if cover and abs(objective(al, sc) - objective(ra, rsc)) < 2e-6 * max(len(al), len(ra)):
+                    ties += 1
+                    ok = True
+                elif cover and max(abs(float(g) - float(ref[dd]['del_penalty'])) for g, dd in zip(pens, sorted(ref))) > 5e-5:
+                    edges += 1
+                    ok = True
+                    print("penalty knife-edge", dict(n=hosts[i][0].shape[1], m=hosts[i][1].shape[1], sample=sample, frac=frac, store=str(store)),
+                          [float(g) for g in pens], [float(ref[dd]['del_penalty']) for dd in sorted(ref)], flush=True)
+            if not ok:
+                bad += 1
+                print("MISMATCH", dict(K=K, amax=amax, W=W, max_full=max_full, sample=sample, nsamp=nsamp, frac=frac, d=d, store=str(store),
+                                       n=hosts[i][0].shape[1], m=hosts[i][1].shape[1], seed=seeds[i]),
+                      repr(res)[:200] if isinstance(res, Exception) else "", repr(ref)[:200] if isinstance(ref, Exception) else "", flush=True)
+                if not isinstance(res, Exception) and not isinstance(ref, Exception):
+                    print("  gpu", res[i][0], [round(float(v), 7) for v in res[i][1]], [float(v) for v in res[i][2]])
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_case_%d.npz" % seeds[i]), v0=hosts[i][0], v1=hosts[i][1])
+                    print("  ref", ref[0]['final_alignments'], [round(float(v), 7) for v in ref[0]['alignment_scores']],
+                          [float(ref[dd]['del_penalty']) for dd in sorted(ref)], flush=True)
+        done += nb
+        if (done // nb) % 10 == 0:
+            print(f"{done} cases, {bad} mismatches, {ties} exact ties, {edges} penalty knife-edges, {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz: {done} cases, {bad} mismatches, {ties} exact ties, {edges} penalty knife-edges, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
