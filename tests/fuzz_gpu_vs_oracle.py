@@ -28,12 +28,12 @@ for p in (os.path.join(ROOT, "speech-vecalign_amd"), os.path.join(ROOT, "oracle"
     sys.path.insert(0, p)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", type=int, default=200)
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=8)
-    a = ap.parse_args()
+def run_sweep(cases, seed, batch=8, verbose=True):
+    """-> (mismatches, exact ties, penalty knife-edges)"""
+    class A:
+        pass
+    a = A()
+    a.cases, a.seed, a.batch = cases, seed, batch
     import torch
     import oracle
     from synth import alignment_types, make_pair, round_bf16
@@ -116,9 +116,19 @@ def main():
                     print("  ref", ref[0]['final_alignments'], [round(float(v), 7) for v in ref[0]['alignment_scores']],
                           [float(ref[dd]['del_penalty']) for dd in sorted(ref)], flush=True)
         done += nb
-        if (done // nb) % 10 == 0:
+        if verbose and (done // nb) % 10 == 0:
             print(f"{done} cases, {bad} mismatches, {ties} exact ties, {edges} penalty knife-edges, {time.time() - t0:.0f} s", flush=True)
     print(f"fuzz: {done} cases, {bad} mismatches, {ties} exact ties, {edges} penalty knife-edges, {time.time() - t0:.0f} s")
+    return bad, ties, edges
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=8)
+    a = ap.parse_args()
+    bad, _, _ = run_sweep(a.cases, a.seed, a.batch)
     sys.exit(1 if bad else 0)
 
 

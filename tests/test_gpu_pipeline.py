@@ -235,3 +235,13 @@ def test_ragged_batch_up_to_8192(orc):
     i = len(shapes) - 1
     ref = orc.vecalign(hosts[i][0].copy(), hosts[i][1].copy(), types, 0.2, 7, 300, 20000, 100, rng=np.random.RandomState(i))
     assert res[i][0] == ref[0]['final_alignments'] and np.abs(res[i][1] - ref[0]['alignment_scores']).max() < SCORE_TOL
+
+
+def test_randomised_sweep_small():
+    """A short run of tests/fuzz_gpu_vs_oracle.py (random sizes, layers, types, band widths, thresholds, storage
+    types, deletions, zero rows; ragged batches): identical spans and scores within 1e-4 in every case that is not an
+    exact tie or a percentile knife-edge of the reference itself (see that file)."""
+    from fuzz_gpu_vs_oracle import run_sweep
+    bad, ties, edges = run_sweep(160, 11, verbose=False)
+    assert bad == 0
+    assert ties + edges <= 3
