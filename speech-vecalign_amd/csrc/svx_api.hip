@@ -45,6 +45,10 @@ struct svx_ctx_ext : svx_ctx {
     hipStream_t aux[3];
     hipEvent_t fork_ev, join_ev[3], stag_ev[3];
     bool aux_ready;
+    // side stream: small latency-bound kernels that do not depend on the streaming passes (the sample sort)
+    hipStream_t side;
+    hipEvent_t side_fork, side_join;
+    bool side_ready;
 };
 
 static inline svx_ctx_ext* X(svx_ctx* c) { return static_cast<svx_ctx_ext*>(c); }
@@ -94,6 +98,7 @@ int svx_create(int device_id, svx_ctx** out) {
     for (int i = 0; i < S_COUNT; i++) { c->ms[i] = -1.0; c->launches[i] = 0; }
     c->n_streams = 1;
     c->aux_ready = false;
+    c->side_ready = false;
     *out = c;
     return SVX_OK;
 }
@@ -103,6 +108,11 @@ int svx_destroy(svx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (X(ctx)->side_ready) {
+        (void)hipStreamDestroy(X(ctx)->side);
+        (void)hipEventDestroy(X(ctx)->side_fork);
+        (void)hipEventDestroy(X(ctx)->side_join);
+    }
     if (X(ctx)->aux_ready) {
         for (int i = 0; i < 3; i++) { (void)hipStreamDestroy(X(ctx)->aux[i]); (void)hipEventDestroy(X(ctx)->join_ev[i]); (void)hipEventDestroy(X(ctx)->stag_ev[i]); }
         (void)hipEventDestroy(X(ctx)->fork_ev);
@@ -559,8 +569,31 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
     for (int i = 0; i < S_COUNT; i++) { cx->ms[i] = 0.0; cx->launches[i] = 0; }
     for (auto& r : cx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     cx->recs.clear();
+    if (!cx->side_ready) {
+        SVX_HIP(ctx, hipStreamCreateWithFlags(&cx->side, hipStreamNonBlocking));
+        SVX_HIP(ctx, hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming));
+        SVX_HIP(ctx, hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming));
+        cx->side_ready = true;
+    }
     auto run_stages = [&](SvxPairDev* dp, int np, hipEvent_t streamed_ev) -> int {
         int rc2;
+        const bool use_side = cx->n_streams <= 1;  // (sub-batch streams already overlap their stages)
+        {
+            // the counting sort of the sampled (x, y) pairs only needs the descriptors: it runs beside the pyramid
+            hipStream_t main_stream = ctx->stream;
+            if (use_side) {
+                SVX_HIP(ctx, hipEventRecord(cx->side_fork, main_stream));
+                SVX_HIP(ctx, hipStreamWaitEvent(cx->side, cx->side_fork, 0));
+                ctx->stream = cx->side;
+            }
+            {
+                StageScope sc(ctx, S_KNOB_SORT);
+                rc2 = svxl_knob_scores(ctx, dp, np, maxL, max_kn, max_n0, dtype, d, 0);
+            }
+            ctx->stream = main_stream;
+            if (rc2) return rc2;
+            if (use_side) SVX_HIP(ctx, hipEventRecord(cx->side_join, cx->side));
+        }
         for (int l = 0; l <= maxL; l++) {
             // pyramid: the streaming pass of level l (S_PYR0 / S_PYRN) and its small helpers
             {
@@ -576,10 +609,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             if ((rc2 = svxl_dense_costs_batch(ctx, dp, np, max_ds0, max_ds1, dtype, d))) return rc2;
             if ((rc2 = svxl_knob_from_dots(ctx, dp, np, max_kn))) return rc2;
         }
-        {
-            StageScope sc(ctx, S_KNOB_SORT);
-            if ((rc2 = svxl_knob_scores(ctx, dp, np, maxL, max_kn, max_n0, dtype, d, 0))) return rc2;
-        }
+        if (use_side) SVX_HIP(ctx, hipStreamWaitEvent(ctx->stream, cx->side_join, 0));
         if (maxL >= 1) {
             StageScope sc(ctx, S_KNOB_SCORES);
             if ((rc2 = svxl_knob_scores(ctx, dp, np, maxL, max_kn, max_n0, dtype, d, 1))) return rc2;
