@@ -504,6 +504,8 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
                 if (cap > max_A[l]) max_A[l] = cap;
                 OFF(Lv.path, (size_t)cap * 2 * sizeof(int));
                 OFF(Lv.path_len, sizeof(int));
+                OFF(Lv.cstart, (size_t)(cap / SVX_BC_TA + 3) * sizeof(int));
+                OFF(Lv.nchunks, sizeof(int));
                 OFF(Lv.costs, (size_t)(T > 0 ? T : 1) * cap * B * sizeof(float));
                 OFF(Lv.boff, (size_t)cap * sizeof(int));
                 OFF(Lv.csum, (size_t)(cap + 2) * B * sizeof(double));
@@ -553,7 +555,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             }
             patch(Lv.kscore); patch(Lv.korder); patch(Lv.kys); patch(Lv.kstart);
             if (!in.del_pen) patch(Lv.pen);
-            patch(Lv.path); patch(Lv.path_len); patch(Lv.costs); patch(Lv.boff); patch(Lv.csum); patch(Lv.xp); patch(Lv.yp); patch(Lv.bpk);
+            patch(Lv.path); patch(Lv.path_len); patch(Lv.cstart); patch(Lv.nchunks); patch(Lv.costs); patch(Lv.boff); patch(Lv.csum); patch(Lv.xp); patch(Lv.yp); patch(Lv.bpk);
             patch(Lv.boff_out);
             if (l > 0) { patch(Lv.align); patch(Lv.scores); patch(Lv.n_align); }
         }

@@ -11,6 +11,9 @@
 #define SVX_PYR_SLOTS 32
 // Band-cost tiling: path points per chunk, band cells per chunk, rows staged per side.
 #define SVX_BC_TA 32
+// The fused pipeline cuts the path into chunks of up to SVX_BC_TAMAX points whose extent on either side still
+// fits the SVX_BC_ROWS staged rows (k_chunk_path); the per-op entry point keeps fixed chunks of SVX_BC_TA.
+#define SVX_BC_TAMAX 64
 #define SVX_BC_TB 16
 #define SVX_BC_ROWS 48
 
@@ -121,6 +124,8 @@ struct SvxLevel {
     double* pen;       // deletion penalty of this level
     int* path;         // [path_cap][2]
     int* path_len;
+    int* cstart;       // [n_chunks + 1] first path point of every band-cost chunk
+    int* nchunks;
     float* costs;      // [A][T][B] (fused pipeline layout: one diagonal's costs are contiguous)
     int* boff;         // [A]
     double* csum;      // [A+2][B]

@@ -379,7 +379,8 @@ __global__ __launch_bounds__(256) void k_knob_from_dots(const SvxPairDev* __rest
 }
 
 // ------------------------------------------------------------------------------ band costs
-constexpr int TA = SVX_BC_TA, TB = SVX_BC_TB, ROWS = SVX_BC_ROWS;
+constexpr int TA = SVX_BC_TA, TAMAX = SVX_BC_TAMAX, TB = SVX_BC_TB, ROWS = SVX_BC_ROWS;
+constexpr int CPT = (TAMAX * TB + 511) / 512;  // band cells per thread in the epilogue
 constexpr int BC_THREADS = 512;
 constexpr int BC_WAVES = BC_THREADS / 64;
 static_assert(BC_WAVES == 8, "unit -> (wave, slot) is decoded with shifts");
@@ -413,7 +414,7 @@ struct BandLds {
 __host__ __device__ inline BandLds band_lds(int kx, int ky, int sw, int ntypes_pass) {
     BandLds L;
     const int NR = (kx + ky) * ROWS;
-    size_t o = (2 * TA + 2 * (SVX_MAX_TYPES + 2)) * sizeof(int);  // spx, spy, tx, ty
+    size_t o = (2 * TAMAX + 2 * (SVX_MAX_TYPES + 2)) * sizeof(int);  // spx, spy, tx, ty
     L.off_rowptr = (o + 15) & ~(size_t)15;
     o = L.off_rowptr + (size_t)NR * sizeof(char*);
     L.off_scal = (o + 15) & ~(size_t)15;
@@ -421,7 +422,7 @@ __host__ __device__ inline BandLds band_lds(int kx, int ky, int sw, int ntypes_p
     L.off_work = (o + 15) & ~(size_t)15;
     L.rs = sw * 128 + 16;
     const size_t slab = (size_t)NR * L.rs;
-    const size_t fs = (size_t)ntypes_pass * TA * TB * sizeof(float);
+    const size_t fs = (size_t)ntypes_pass * TAMAX * TB * sizeof(float);
     const size_t epi = fs + (size_t)BC_WAVES * DUMP_UNIT * sizeof(float);  // Fs + at least one dump round
     L.work_bytes = slab > epi ? slab : epi;
     L.total = L.off_work + L.work_bytes;
@@ -459,7 +460,7 @@ __device__ __forceinline__ void slab_store(const uint4* pre, char* slab, unsigne
 
 // NPT = 16-byte pieces a thread stages per k-slab: ceil((kx+ky)*48*8*SW / 512)
 template <typename E, int NPT, int SW>
-__device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky, int chunk_a, int chunk_b, char* smem) {
+__device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky, int a0, int TAe, int chunk_b, char* smem) {
     using S = typename E::storage;
     using M = Mma<E>;
     constexpr int RSB = SW * 128 + 16;
@@ -470,16 +471,14 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
     constexpr int TPP = BC_WAVES * UPW / 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = 2 * g.W;
-    const int a0 = chunk_a * TA;
-    const int TAe = (g.A - a0) < TA ? (g.A - a0) : TA;
     const int b0 = chunk_b * TB;
     const int TBe = (B - b0) < TB ? (B - b0) : TB;
     const int NR = (kx + ky) * ROWS;
     const int npieces = NR * 8 * SW;
     const BandLds L = band_lds(kx, ky, SW, ty.n < TPP ? ty.n : TPP);
     int* spx = reinterpret_cast<int*>(smem);
-    int* spy = spx + TA;
-    int* ltx = spy + TA;                      // alignment type sizes (kernel-argument arrays cannot be indexed
+    int* spy = spx + TAMAX;
+    int* ltx = spy + TAMAX;                    // alignment type sizes (kernel-argument arrays cannot be indexed
     int* lty = ltx + (SVX_MAX_TYPES + 2);     //  dynamically without a trip through scratch)
     const char** rowptr = reinterpret_cast<const char**>(smem + L.off_rowptr);
     float* snrm = reinterpret_cast<float*>(smem + L.off_scal);  // [NR] normaliser of each staged row
@@ -533,18 +532,26 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
     const int nxt = NXn <= 16 ? 1 : (NXn <= 32 ? 2 : 3);
     const int nyt = NYn <= 16 ? 1 : (NYn <= 32 ? 2 : 3);
 
-    // this thread's output cell (one per thread: TAe * TBe <= 512)
+    // this thread's output cells (CPT per thread: TAe * TBe <= TAMAX * TB)
     const int ncells = TAe * TBe;
-    const int c_ai = tid / TBe, c_bi = tid - c_ai * TBe;
-    int c_xloc = 0, c_yloc = 0;
-    bool c_in = false;
-    if (tid < ncells) {
-        const int yy = spy[c_ai] - g.W + b0 + c_bi;
-        const int xx = (a0 + c_ai) - yy;
-        c_xloc = xx - X0;  // 0 <= xloc, yloc <= 46 for a unit-step path
-        c_yloc = yy - Y0;
-        c_in = xx >= 0 && xx < g.n && yy >= 0 && yy < g.m;
-        if (c_xloc < 0 || c_xloc >= ROWS || c_yloc < 0 || c_yloc >= ROWS) { c_xloc = 0; c_yloc = 0; c_in = false; }
+    int c_ai[CPT], c_bi[CPT], c_xloc[CPT], c_yloc[CPT];
+    bool c_in[CPT];
+#pragma unroll
+    for (int cc = 0; cc < CPT; cc++) {
+        const int cell = tid + cc * BC_THREADS;
+        c_ai[cc] = cell / TBe;
+        c_bi[cc] = cell - c_ai[cc] * TBe;
+        c_xloc[cc] = 0;
+        c_yloc[cc] = 0;
+        c_in[cc] = false;
+        if (cell < ncells) {
+            const int yy = spy[c_ai[cc]] - g.W + b0 + c_bi[cc];
+            const int xx = (a0 + c_ai[cc]) - yy;
+            c_xloc[cc] = xx - X0;  // 0 <= xloc, yloc < ROWS for a unit-step path
+            c_yloc[cc] = yy - Y0;
+            c_in[cc] = xx >= 0 && xx < g.n && yy >= 0 && yy < g.m;
+            if (c_xloc[cc] < 0 || c_xloc[cc] >= ROWS || c_yloc[cc] < 0 || c_yloc[cc] >= ROWS) { c_xloc[cc] = 0; c_yloc[cc] = 0; c_in[cc] = false; }
+        }
     }
 
     for (int pass = 0; pass * TPP < ty.n; pass++) {
@@ -641,8 +648,8 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
         // Rounds of SR unit slots: dump -> every thread looks its cell up in each dumped unit whose x tile
         // contains the cell's row -> cost formula -> Fs.  Finally Fs is written out coalesced.
         float* Fs = reinterpret_cast<float*>(slab);
-        float* dump = Fs + (size_t)ntp * TA * TB;
-        const int du = (int)((L.work_bytes - (size_t)ntp * TA * TB * sizeof(float)) / (DUMP_UNIT * sizeof(float)));
+        float* dump = Fs + (size_t)ntp * TAMAX * TB;
+        const int du = (int)((L.work_bytes - (size_t)ntp * TAMAX * TB * sizeof(float)) / (DUMP_UNIT * sizeof(float)));
         const int SR = du / BC_WAVES >= UPW ? UPW : (du / BC_WAVES < 1 ? 1 : du / BC_WAVES);
         const int nslots = (nunits + BC_WAVES - 1) / BC_WAVES;
         for (int s0 = 0; s0 < nslots; s0 += SR) {
@@ -657,8 +664,10 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
                 }
             }
             __syncthreads();
-            if (tid < ncells) {
-                const int xq = c_xloc >> 4;
+#pragma unroll
+            for (int cc = 0; cc < CPT; cc++) {
+                if (tid + cc * BC_THREADS >= ncells) continue;
+                const int xq = c_xloc[cc] >> 4;
                 const int ulo = s0 * BC_WAVES, uhi = (s0 + SR) * BC_WAVES < nunits ? (s0 + SR) * BC_WAVES : nunits;
                 // units of this round whose x tile holds my row: u = nxt*tl + xq
                 for (int tl = (ulo - xq + nxt - 1) / nxt; nxt * tl + xq < uhi; tl++) {
@@ -666,14 +675,14 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
                     const int t = pass * TPP + tl;
                     const int p = ltx[t], q = lty[t];
                     float c = __builtin_inff();
-                    if (c_in) {
-                        const int rx = (p - 1) * ROWS + c_xloc, ry = (kx + q - 1) * ROWS + c_yloc;
-                        float dsum = dump[(u - ulo) * DUMP_UNIT + (c_xloc & 15) * ROWS + c_yloc];
-                        if (ksplit) dsum += dump[(u - ulo + 4) * DUMP_UNIT + (c_xloc & 15) * ROWS + c_yloc];
+                    if (c_in[cc]) {
+                        const int rx = (p - 1) * ROWS + c_xloc[cc], ry = (kx + q - 1) * ROWS + c_yloc[cc];
+                        float dsum = dump[(u - ulo) * DUMP_UNIT + (c_xloc[cc] & 15) * ROWS + c_yloc[cc]];
+                        if (ksplit) dsum += dump[(u - ulo + 4) * DUMP_UNIT + (c_xloc[cc] & 15) * ROWS + c_yloc[cc]];
                         const float sumx = dsum * sinv[rx] * sinv[ry];
                         c = cost_formula(sumx, p, q, snrm[rx], snrm[ry]);
                     }
-                    Fs[((size_t)c_ai * ntp + tl) * TB + c_bi] = c;
+                    Fs[((size_t)c_ai[cc] * ntp + tl) * TB + c_bi[cc]] = c;
                 }
             }
             __syncthreads();
@@ -694,7 +703,8 @@ __device__ void band_block(const BandArgs& g, const SvxTypes& ty, int kx, int ky
 template <typename E, int NPT, int SW>
 __global__ __launch_bounds__(BC_THREADS) void k_band_costs(BandArgs g, SvxTypes ty, int kx, int ky, int nchunk_b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    band_block<E, NPT, SW>(g, ty, kx, ky, blockIdx.x / nchunk_b, blockIdx.x % nchunk_b, smem);
+    const int a0 = (blockIdx.x / nchunk_b) * TA;
+    band_block<E, NPT, SW>(g, ty, kx, ky, a0, (g.A - a0) < TA ? (g.A - a0) : TA, blockIdx.x % nchunk_b, smem);
 }
 
 // depth 0 uses the final types on the raw rows; deeper levels use (1,1) on normalised fp32 layer 0
@@ -720,7 +730,8 @@ __global__ __launch_bounds__(BC_THREADS) void k_band_costs_batch(const SvxPairDe
     BandArgs g;
     g.A = *Lv.path_len;
     const int chunk_a = item / nchunk_b;
-    if (g.A <= 0 || chunk_a * TA >= g.A) return;
+    if (g.A <= 0 || chunk_a >= *Lv.nchunks) return;
+    const int a0 = Lv.cstart[chunk_a], TAe = Lv.cstart[chunk_a + 1] - a0;
     g.n = Lv.n[0];
     g.m = Lv.n[1];
     g.d = P.d;
@@ -736,7 +747,7 @@ __global__ __launch_bounds__(BC_THREADS) void k_band_costs_batch(const SvxPairDe
     g.boff = Lv.boff;
     g.status = P.status;
     g.atb = 1;
-    band_block<E, NPT, SW>(g, ty, kx, ky, chunk_a, item % nchunk_b, smem);
+    band_block<E, NPT, SW>(g, ty, kx, ky, a0, TAe, item % nchunk_b, smem);
 }
 
 inline int nch_f32(int d) {

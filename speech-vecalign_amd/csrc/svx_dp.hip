@@ -926,6 +926,59 @@ __global__ __launch_bounds__(256) void k_search_path_batch(const SvxPairDev* __r
     }
 }
 
+// Band-cost chunks of the fused pipeline: as many path points as possible (<= SVX_BC_TAMAX) whose source and
+// target extents both stay within SVX_BC_ROWS - SVX_BC_TB rows, so that a chunk's cells never leave the rows its
+// workgroup stages.  The end of the chunk that starts at s is found for every s at once (the path is monotone:
+// binary search), then thread 0 hops from chunk start to chunk start.
+__global__ __launch_bounds__(256) void k_chunk_path(const SvxPairDev* __restrict__ pairs, int depth, int lds_ints) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* nxt = reinterpret_cast<int*>(smem);
+    const SvxPairDev& P = pairs[blockIdx.x];
+    if (depth > P.L || (depth == P.L && P.L > 0)) return;
+    const SvxLevel& Lv = P.lev[depth];
+    const int A = *Lv.path_len;
+    constexpr int LIM = SVX_BC_ROWS - SVX_BC_TB;
+    if (A <= 0 || *P.status != 0) {
+        if (threadIdx.x == 0) *Lv.nchunks = 0;
+        return;
+    }
+    const int2* path = reinterpret_cast<const int2*>(Lv.path);
+    if (A <= lds_ints) {
+        for (int s0 = threadIdx.x; s0 < A; s0 += 256) {
+            const int2 p0 = path[s0];
+            int lo = s0 + 1, hi = (s0 + SVX_BC_TAMAX) < A ? (s0 + SVX_BC_TAMAX) : A;
+            while (lo < hi) {  // smallest i in (s0, hi] that is hi or leaves the window
+                const int mid = (lo + hi) >> 1;
+                const int2 p = path[mid];
+                if (p.x - p0.x > LIM || p.y - p0.y > LIM) hi = mid;
+                else lo = mid + 1;
+            }
+            nxt[s0] = lo;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int nc = 0;
+            for (int s0 = 0; s0 < A; s0 = nxt[s0]) Lv.cstart[nc++] = s0;
+            Lv.cstart[nc] = A;
+            *Lv.nchunks = nc;
+        }
+    } else if (threadIdx.x == 0) {
+        int nc = 0, s0 = 0;
+        int2 p0 = path[0];
+        Lv.cstart[0] = 0;
+        for (int i = 1; i < A; i++) {
+            const int2 p = path[i];
+            if (i - s0 >= SVX_BC_TAMAX || p.x - p0.x > LIM || p.y - p0.y > LIM) {
+                Lv.cstart[++nc] = i;
+                s0 = i;
+                p0 = p;
+            }
+        }
+        Lv.cstart[++nc] = A;
+        *Lv.nchunks = nc;
+    }
+}
+
 // ------------------------------------------------------------------------------ deletion penalty
 // DeletionKnob (dp_utils.py:50-79) with numpy's arithmetic: float32 bin edges i*(max/1000),
 // density histogram, float64 cdf, 27 interior knots k/28, np.interp at `frac`.
@@ -1229,6 +1282,13 @@ int svxl_search_path_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, i
         SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_search_path_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(k_search_path_batch, dim3(n_pairs), dim3(256), smem, ctx->stream, pairs, depth, rows);
     SVX_LAUNCH_CHECK(ctx, "k_search_path_batch");
+    int ints = max_rows + 4;  // path points of the longest pair (= its n + m + 4 bound)
+    if (ints > 36 * 1024) ints = 36 * 1024;
+    const size_t csmem = (size_t)ints * sizeof(int);
+    if (csmem > 64 * 1024)
+        SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_chunk_path, hipFuncAttributeMaxDynamicSharedMemorySize, (int)csmem));
+    hipLaunchKernelGGL(k_chunk_path, dim3(n_pairs), dim3(256), csmem, ctx->stream, pairs, depth, ints);
+    SVX_LAUNCH_CHECK(ctx, "k_chunk_path");
     return SVX_OK;
 }
 
