@@ -572,7 +572,9 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
     for (auto& r : cx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     cx->recs.clear();
     if (!cx->side_ready) {
-        SVX_HIP(ctx, hipStreamCreateWithFlags(&cx->side, hipStreamNonBlocking));
+        int prio_lo = 0, prio_hi = 0;
+        SVX_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // (lowest, highest): the side work only fills gaps
+        SVX_HIP(ctx, hipStreamCreateWithPriority(&cx->side, hipStreamNonBlocking, prio_lo));
         SVX_HIP(ctx, hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming));
         SVX_HIP(ctx, hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming));
         cx->side_ready = true;
