@@ -175,7 +175,7 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
     using R = Row<E, NCH>;
     constexpr int EPL = R::EPL;
     constexpr int DP = EPL * SVX_WAVE;  // padded row length
-    constexpr int DEPTH = PAIR ? 2 : (E::VEC == 8 ? 3 : 1);  // rows in flight per wave beyond the one being processed
+    constexpr int DEPTH = PAIR ? 2 : (E::VEC == 8 ? 4 : 1);  // rows in flight per wave beyond the one being processed
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float* mu_l = lds;
     float* rb_l = lds + DP;
