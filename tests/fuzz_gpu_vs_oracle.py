@@ -28,7 +28,7 @@ for p in (os.path.join(ROOT, "speech-vecalign_amd"), os.path.join(ROOT, "oracle"
     sys.path.insert(0, p)
 
 
-def run_sweep(cases, seed, batch=8, verbose=True):
+def run_sweep(cases, seed, batch=8, verbose=True, max_size=900):
     """-> (mismatches, exact ties, penalty knife-edges)"""
     class A:
         pass
@@ -56,7 +56,7 @@ def run_sweep(cases, seed, batch=8, verbose=True):
         nb = min(a.batch, a.cases - done)
         hosts, devs = [], []
         for i in range(nb):
-            n, m = int(rs.randint(1, 900)), int(rs.randint(1, 900))
+            n, m = int(rs.randint(1, max_size)), int(rs.randint(1, max_size))
             if rs.rand() < 0.15:
                 n, m = int(rs.randint(1, 12)), int(rs.randint(1, 12))
             v0, v1 = make_pair(n, m, K, d, int(rs.randint(1 << 30)), deletions=int(rs.randint(0, 6)) if min(n, m) > 12 else 0,
@@ -127,8 +127,9 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--max_size", type=int, default=900, help="documents have 1 .. max_size-1 segments")
     a = ap.parse_args()
-    bad, _, _ = run_sweep(a.cases, a.seed, a.batch)
+    bad, _, _ = run_sweep(a.cases, a.seed, a.batch, max_size=a.max_size)
     sys.exit(1 if bad else 0)
 
 
