@@ -180,11 +180,23 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
     float* mu_l = lds;
     float* rb_l = lds + DP;
     float* red = lds + 2 * DP;
+    // mean / rbar are kept lane-major: the 16-byte group g of lane l sits at float4 index g * 64 + l, so that a
+    // wave's ds_read_b128 touches consecutive addresses (the row's own column map would stride them by VEC floats)
     for (int c = threadIdx.x; c < DP; c += blockDim.x) {
-        mu_l[c] = (mean && c < d) ? mean[c] : 0.f;
-        rb_l[c] = (rbar && c < d) ? rbar[c] : 0.f;
+        const int ch = c / (SVX_WAVE * E::VEC), l = (c / E::VEC) % SVX_WAVE, i = c % E::VEC;
+        const int e = ch * E::VEC + i;
+        const int at = ((e >> 2) * SVX_WAVE + l) * 4 + (e & 3);
+        mu_l[at] = (mean && c < d) ? mean[c] : 0.f;
+        rb_l[at] = (rbar && c < d) ? rbar[c] : 0.f;
     }
     __syncthreads();
+    auto lane_major = [&](const float* tab, float* out) {
+#pragma unroll
+        for (int g4 = 0; g4 < EPL / 4; g4++) {
+            const float4 t = *reinterpret_cast<const float4*>(tab + (g4 * SVX_WAVE + lane) * 4);
+            out[4 * g4 + 0] = t.x; out[4 * g4 + 1] = t.y; out[4 * g4 + 2] = t.z; out[4 * g4 + 3] = t.w;
+        }
+    };
     float cs[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; e++) cs[e] = 0.f;
@@ -209,7 +221,7 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
             if (r + DEPTH < r1) fetch_raw<E, NCH, PAIR>(rows, inv0, r + DEPTH, d, lane, ring[s]);
             if (mean) {
                 float mu[EPL];
-                R::loadf(mu_l, DP, lane, mu);
+                lane_major(mu_l, mu);
 #pragma unroll
                 for (int e = 0; e < EPL; e++) x[e] = x[e] - mu[e];  // columns >= d: 0 - 0
             }
@@ -223,7 +235,7 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
             for (int e = 0; e < EPL; e++) x[e] = x[e] * rden;
             if (rbar) {
                 float rbv[EPL];
-                R::loadf(rb_l, DP, lane, rbv);
+                lane_major(rb_l, rbv);
                 float dt = 0.f;
 #pragma unroll
                 for (int e = 0; e < EPL; e++) dt += x[e] * rbv[e];
