@@ -532,7 +532,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         if (top.n[1] > max_ds1) max_ds1 = top.n[1];
         OFF(P.dcost, (size_t)top.n[0] * top.n[1] * sizeof(float));
         OFF(P.ddot, (size_t)top.n[0] * top.n[1] * sizeof(float));
-        OFF(P.dbp, (size_t)(top.n[0] + 1) * (top.n[1] + 1) * sizeof(int));
+        OFF(P.dbp, (size_t)(top.n[0] + top.n[1] + 1) * (top.n[0] + 1) * sizeof(int));  // (anti-diagonal, row) layout
     }
 #undef OFF
     if ((rc = arena_reserve(ctx, bump.off))) return rc;

@@ -146,7 +146,7 @@ struct SvxPairDev {
     int norm_override[2];
     float* dcost;      // dense stage at level L: [s0][s1]
     float* ddot;       // [s0][s1] raw dot products of the same stage (L >= 1): the level's sampled scores read them
-    int* dbp;          // [s0+1][s1+1]
+    int* dbp;          // [s0+s1+1][s0+1]: back-pointers of the dense stage by (anti-diagonal, row)
     int* status;       // info[1]
     SvxLevel lev[SVX_MAX_LEVELS];
 };

@@ -28,19 +28,34 @@ struct DenseDpArgs {
     int s0, s1;
     float pen;
     double* csum;  // [s0+1][s1+1] or null
-    int* bp;       // [s0+1][s1+1]
+    int* bp;       // [s0+1][s1+1]; or, with diag != 0, [s0+s1+1][s0+1] indexed by (anti-diagonal, row):
+                   // neighbouring threads then store neighbouring words (fused pipeline only)
+    int diag;
 };
 
 __device__ void dense_dp_block(const DenseDpArgs& g, double* ring) {
     const int rmax = g.s0 + 1, cmax = g.s1 + 1;
     const int tid = threadIdx.x, nt = blockDim.x;
     const double pen_d = (double)g.pen;
+    // The cost of this thread's first cell of diagonal k+1 is fetched while diagonal k is being finished (costs do
+    // not depend on the DP state), so that no global load sits between two barriers.
+    auto cost_of = [&](int k, int r) -> float {
+        const int c = k - r;
+        return (r >= 1 && r <= g.s0 && c >= 1 && c <= g.s1) ? g.cost[(size_t)(r - 1) * g.s1 + (c - 1)] : 0.f;
+    };
+    float cnext = cost_of(0, tid);
     for (int k = 0; k <= g.s0 + g.s1; k++) {
         const int rlo = k - g.s1 > 0 ? k - g.s1 : 0;
         const int rhi = k < g.s0 ? k : g.s0;
         double* cur = ring + (size_t)(k % 3) * rmax;
         const double* p1 = ring + (size_t)((k + 2) % 3) * rmax;  // diagonal k-1
         const double* p2 = ring + (size_t)((k + 1) % 3) * rmax;  // diagonal k-2
+        const float cfirst = cnext;
+        {
+            const int k1 = k + 1;
+            const int rlo1 = k1 - g.s1 > 0 ? k1 - g.s1 : 0;
+            cnext = cost_of(k1, rlo1 + tid);
+        }
         for (int r = rlo + tid; r <= rhi; r += nt) {
             const int c = k - r;
             double v;
@@ -53,7 +68,8 @@ __device__ void dense_dp_block(const DenseDpArgs& g, double* ring) {
                 v = (double)((float)r * g.pen);
                 b = 2;
             } else {
-                const double cost0 = p2[r - 1] + (double)g.cost[(size_t)(r - 1) * g.s1 + (c - 1)];
+                const float cf = (r == rlo + tid) ? cfirst : g.cost[(size_t)(r - 1) * g.s1 + (c - 1)];
+                const double cost0 = p2[r - 1] + (double)cf;
                 const double cost1 = p1[r] + pen_d;
                 const double cost2 = p1[r - 1] + pen_d;
                 v = cost0;
@@ -62,7 +78,7 @@ __device__ void dense_dp_block(const DenseDpArgs& g, double* ring) {
                 if (cost2 < v) { v = cost2; b = 2; }
             }
             cur[r] = v;
-            g.bp[(size_t)r * cmax + c] = b;
+            g.bp[g.diag ? (size_t)k * rmax + r : (size_t)r * cmax + c] = b;
             if (g.csum) g.csum[(size_t)r * cmax + c] = v;
         }
         __syncthreads();
@@ -71,13 +87,13 @@ __device__ void dense_dp_block(const DenseDpArgs& g, double* ring) {
 
 // Walks bp from (s0,s1) to (0,0); rows (x_start,x_len,y_start,y_len) land in document order.
 // Single thread.  Returns the count or -SVX_ERR_BP.
-__device__ int dense_traceback_thread(const int* bp, int s0, int s1, int* out) {
-    const int cmax = s1 + 1;
+__device__ int dense_traceback_thread(const int* bp, int s0, int s1, int* out, int diag = 0) {
+    const int cmax = s1 + 1, rmax = s0 + 1;
     int xx = s0, yy = s1, n = 0;
     const int cap = s0 + s1;
     while (!(xx == 0 && yy == 0)) {
         if (n >= cap) return -SVX_ERR_BP;
-        const int b = bp[(size_t)xx * cmax + yy];
+        const int b = bp[diag ? (size_t)(xx + yy) * rmax + xx : (size_t)xx * cmax + yy];
         int* o = out + 4 * (size_t)(cap - 1 - n);  // fill from the back: document order at the end
         if (b == 0) { o[0] = xx - 1; o[1] = 1; o[2] = yy - 1; o[3] = 1; xx--; yy--; }
         else if (b == 1) { o[0] = xx; o[1] = 0; o[2] = yy - 1; o[3] = 1; yy--; }
@@ -113,9 +129,10 @@ __global__ __launch_bounds__(256) void k_dense_stage_batch(const SvxPairDev* __r
     g.pen = (float)(*Lv.pen);  // the reference passes the float64 penalty through a C float parameter
     g.csum = nullptr;
     g.bp = P.dbp;
+    g.diag = 1;
     dense_dp_block(g, reinterpret_cast<double*>(smem));
     if (threadIdx.x == 0) {
-        const int n = dense_traceback_thread(P.dbp, g.s0, g.s1, Lv.align);
+        const int n = dense_traceback_thread(P.dbp, g.s0, g.s1, Lv.align, 1);
         *Lv.n_align = n;
         if (n < 0) *P.status = -n;
     }
@@ -1082,7 +1099,7 @@ inline int dp_threads(int B) {
 int svxl_dense_dp(svx_ctx* ctx, const float* cost, int s0, int s1, float pen, double* csum, int* bp) {
     const size_t smem = 3 * (size_t)(s0 + 1) * sizeof(double);
     if (smem > 150 * 1024) return svx_fail(ctx, SVX_ERR_ARG, "dense_dp: %d rows exceed the LDS ring (max 6399)", s0);
-    DenseDpArgs g{cost, s0, s1, pen, csum, bp};
+    DenseDpArgs g{cost, s0, s1, pen, csum, bp, 0};
     if (smem > 64 * 1024)
         SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_dense_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(k_dense_dp, dim3(1), dim3(256), smem, ctx->stream, g);
