@@ -101,45 +101,65 @@ struct DenseArgs {
     float* dots;     // optional [s0][s1]: the normalised dot products themselves
 };
 
+// One workgroup = a DT x DT block of the cost matrix (DT = 64: every wave owns 32 x 32 = four MFMA tiles, so that a
+// staged row is used against 64 rows of the other side instead of 32).
+constexpr int DT = 64;
 template <typename E>
 __device__ void dense_block(const DenseArgs& g, int bx, int by, char* smem) {
     using S = typename E::storage;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // 4 waves: 2x2 tiles of 16
-    const char** rowptr = reinterpret_cast<const char**>(smem);    // 64 rows
-    char* slab = smem + 64 * sizeof(char*);
-    const int x0 = bx * 32, y0 = by * 32;
-    if (tid < 64) {
-        const int side = tid >> 5, loc = tid & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // 4 waves: 2 x 2 blocks of 32
+    const char** rowptr = reinterpret_cast<const char**>(smem);    // 2 * DT rows: x rows then y rows
+    char* slab = smem + 2 * DT * sizeof(char*);
+    const int x0 = bx * DT, y0 = by * DT;
+    if (tid < 2 * DT) {
+        const int side = tid >= DT, loc = tid - side * DT;
         const int gi = (side ? y0 : x0) + loc;
         const int nn = side ? g.s1 : g.s0;
         const char* base = reinterpret_cast<const char*>(side ? g.v1 : g.v0);
         rowptr[tid] = (gi < nn) ? base + (size_t)gi * g.d * sizeof(S) : nullptr;
     }
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const int xt = wave >> 1, yt = wave & 1;
     for (int k0 = 0; k0 < g.d; k0 += Mma<E>::KS) {
         __syncthreads();
-        stage_slab<E>(slab, rowptr, 64, k0, g.d, tid, blockDim.x);
+        stage_slab<E>(slab, rowptr, 2 * DT, k0, g.d, tid, blockDim.x);
         __syncthreads();
-        const char* ap = slab + xt * 16 * RS + Mma<E>::lane_off(lane);
-        const char* bp = slab + (32 + yt * 16) * RS + Mma<E>::lane_off(lane);
+        const char* ap = slab + xt * 32 * RS + Mma<E>::lane_off(lane);
+        const char* bp = slab + (DT + yt * 32) * RS + Mma<E>::lane_off(lane);
 #pragma unroll
-        for (int ks = 0; ks < Mma<E>::NK; ks++)
-            Mma<E>::mma(acc, Mma<E>::load(ap + ks * Mma<E>::KSTEP_BYTES), Mma<E>::load(bp + ks * Mma<E>::KSTEP_BYTES));
-    }
-    const int y = y0 + yt * 16 + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int x = x0 + xt * 16 + (lane >> 4) * 4 + r;
-        if (x < g.s0 && y < g.s1) {
-            float sumx = acc[r];
-            if (g.inv0) sumx = sumx * g.inv0[x] * g.inv1[y];
-            float c = cost_formula(sumx, 1, 1, g.n0[x], g.n1[y]);
-            c = (c * (float)g.mul0) * (float)g.mul1;  // dp_core.pyx:75 (float * int)
-            g.costs[(size_t)x * g.s1 + y] = c;
-            if (g.dots) g.dots[(size_t)x * g.s1 + y] = sumx;
+        for (int ks = 0; ks < Mma<E>::NK; ks++) {
+            const typename Mma<E>::frag a0 = Mma<E>::load(ap + ks * Mma<E>::KSTEP_BYTES);
+            const typename Mma<E>::frag a1 = Mma<E>::load(ap + 16 * RS + ks * Mma<E>::KSTEP_BYTES);
+            const typename Mma<E>::frag b0 = Mma<E>::load(bp + ks * Mma<E>::KSTEP_BYTES);
+            const typename Mma<E>::frag b1 = Mma<E>::load(bp + 16 * RS + ks * Mma<E>::KSTEP_BYTES);
+            Mma<E>::mma(acc[0][0], a0, b0);
+            Mma<E>::mma(acc[0][1], a0, b1);
+            Mma<E>::mma(acc[1][0], a1, b0);
+            Mma<E>::mma(acc[1][1], a1, b1);
         }
     }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int y = y0 + yt * 32 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int x = x0 + xt * 32 + i * 16 + (lane >> 4) * 4 + r;
+                if (x < g.s0 && y < g.s1) {
+                    float sumx = acc[i][j][r];
+                    if (g.inv0) sumx = sumx * g.inv0[x] * g.inv1[y];
+                    float c = cost_formula(sumx, 1, 1, g.n0[x], g.n1[y]);
+                    c = (c * (float)g.mul0) * (float)g.mul1;  // dp_core.pyx:75 (float * int)
+                    g.costs[(size_t)x * g.s1 + y] = c;
+                    if (g.dots) g.dots[(size_t)x * g.s1 + y] = sumx;
+                }
+            }
+        }
 }
 
 template <typename E>
@@ -157,7 +177,7 @@ __global__ __launch_bounds__(256) void k_dense_costs_batch(const SvxPairDev* __r
     DenseArgs g;
     g.s0 = Lv.n[0];
     g.s1 = Lv.n[1];
-    if ((int)blockIdx.x * 32 >= g.s0 || (int)blockIdx.y * 32 >= g.s1) return;
+    if ((int)blockIdx.x * DT >= g.s0 || (int)blockIdx.y * DT >= g.s1) return;
     g.d = P.d;
     g.v0 = LV0 ? P.v[0] : (const void*)Lv.P[0];
     g.v1 = LV0 ? P.v[1] : (const void*)Lv.P[1];
@@ -759,7 +779,7 @@ inline int nch_16(int d) {
     return c <= 1 ? 1 : c <= 2 ? 2 : 4;
 }
 
-constexpr size_t DENSE_SMEM = 64 * sizeof(char*) + 64 * RS;
+constexpr size_t DENSE_SMEM = 2 * DT * sizeof(char*) + 2 * DT * RS;
 
 }  // namespace
 
@@ -767,7 +787,7 @@ int svxl_dense_costs(svx_ctx* ctx, const float* v0, int s0, const float* v1, int
                      const float* n1, int mul0, int mul1, float* costs) {
     if (s0 <= 0 || s1 <= 0) return SVX_OK;
     DenseArgs g{v0, v1, s0, s1, d, nullptr, nullptr, n0, n1, mul0, mul1, costs, nullptr};
-    hipLaunchKernelGGL(k_dense_costs<ElemF32>, dim3((s0 + 31) / 32, (s1 + 31) / 32), dim3(256), DENSE_SMEM, ctx->stream, g);
+    hipLaunchKernelGGL(k_dense_costs<ElemF32>, dim3((s0 + DT - 1) / DT, (s1 + DT - 1) / DT), dim3(256), DENSE_SMEM, ctx->stream, g);
     SVX_LAUNCH_CHECK(ctx, "k_dense_costs");
     return SVX_OK;
 }
@@ -775,7 +795,7 @@ int svxl_dense_costs(svx_ctx* ctx, const float* v0, int s0, const float* v1, int
 int svxl_dense_costs_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int max_s0, int max_s1, int dtype, int d) {
     (void)d;
     if (n_pairs <= 0 || max_s0 <= 0 || max_s1 <= 0) return SVX_OK;
-    dim3 grid((max_s0 + 31) / 32, (max_s1 + 31) / 32, n_pairs);
+    dim3 grid((max_s0 + DT - 1) / DT, (max_s1 + DT - 1) / DT, n_pairs);
     hipLaunchKernelGGL((k_dense_costs_batch<ElemF32, false>), grid, dim3(256), DENSE_SMEM, ctx->stream, pairs);
     if (dtype == SVX_F32)
         hipLaunchKernelGGL((k_dense_costs_batch<ElemF32, true>), grid, dim3(256), DENSE_SMEM, ctx->stream, pairs);
