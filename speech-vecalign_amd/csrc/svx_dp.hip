@@ -479,19 +479,24 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
                 }
                 return r;
             };
-            Part part = T > 0 ? partial(0) : Part{inf, 0x7fffffff};
-            unsigned nw = node[bb];
-            for (int a = a0; a < a_end; a++) {
-                const int i = a - a0;
-                const int inext = a + 1 < a_end ? i + 1 : i;  // (the last diagonal re-reads itself: no branch)
-                // stage 1 of diagonal a+1 (independent of what follows)
-                const unsigned nnw = node[inext * B + bb];
-                Part npart{inf, 0x7fffffff};
-                if (T > 0) npart = partial(inext);
-                // stage 2 of diagonal a: the deletions, from the register copy of diagonal a-1
+            // group merge of one lane's best type move (shared by both sweeps below)
+            auto merge = [&](Part r) {
+                if (G == 4) {
+                    const double ob = xchg16_f64(r.tot, lane);
+                    const int ok2 = (int)xchg16_u32((unsigned)r.key, lane);
+                    if (ob < r.tot || (ob == r.tot && ok2 < r.key)) { r.tot = ob; r.key = ok2; }
+                }
+                if (G >= 2) {
+                    const double ob = xchg32_f64(r.tot, lane);
+                    const int ok2 = (int)xchg32_u32((unsigned)r.key, lane);
+                    if (ob < r.tot || (ob == r.tot && ok2 < r.key)) { r.tot = ob; r.key = ok2; }
+                }
+                return r;
+            };
+            // stage 2 of diagonal a: the deletions, from the register copy of diagonal a-1 (p01 / p10), then the
+            // node's border / outside cases; stores the node and returns its csum
+            auto finish = [&](int a, int i, unsigned nw, const Part& part, double p01, double p10) {
                 const int kind = nw & 3, s01 = (nw >> 2) & 127, s10 = (nw >> 9) & 127;
-                const double p01 = __shfl(cur, gbase + (s01 < B ? s01 : bb), SVX_WAVE);
-                const double p10 = __shfl(cur, gbase + (s10 < B ? s10 : bb), SVX_WAVE);
                 double best = part.tot;
                 int bk = part.key;
                 const double t01 = p01 + pen, t10 = p10 + pen;
@@ -501,16 +506,93 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
                 const double border = pen * (double)a;
                 best = kind == 0 ? (bk != 0x7fffffff ? best : inf) : (kind == 3 ? inf : border);
                 bk = kind == 0 ? bk : (kind == 1 ? key01 : (kind == 2 ? key10 : 0x7fffffff));
-                cur = best;
                 if (b < B && grp == 0) {
                     ring[slot * B + b] = best;
                     obest[i * B + b] = best;
                     okey[i * B + b] = bk;
                 }
-                part = npart;
-                nw = nnw;
-                slot = (slot + 1 == RD) ? 0 : slot + 1;
-                __builtin_amdgcn_wave_barrier();
+                return best;
+            };
+            if (unrolled) {
+                // Software pipeline over the LDS round trips: at the top of the step for diagonal a the wave issues
+                // together (1) the two neighbour fetches of diagonal a-1 for stage 2 of a, (2) the ring reads of the
+                // type moves of a+1, whose slots and costs were fetched one step earlier, and (3) the table rows of
+                // a+2 -- and then waits once.
+                const int nrows = a_end - a0;
+                int sl1[DPF_TPL];
+                float cs1[DPF_TPL];
+                Part part{inf, 0x7fffffff};
+                {
+                    double pv0[DPF_TPL];
+                    float cs0[DPF_TPL];
+                    const int i1 = nrows > 1 ? 1 : 0;
+#pragma unroll
+                    for (int j = 0; j < DPF_TPL; j++) {
+                        const int o = toff[j];
+                        cs0[j] = cost[o];
+                        pv0[j] = ring[tval[j] ? (int)idx[o] : RD * B];
+                        sl1[j] = tval[j] ? (int)idx[i1 * TB + o] : RD * B;
+                        cs1[j] = cost[i1 * TB + o];
+                    }
+#pragma unroll
+                    for (int j = 0; j < DPF_TPL; j++) {
+                        const double tot = pv0[j] + (double)cs0[j];
+                        if (tot < part.tot) { part.tot = tot; part.key = tkey[j]; }
+                    }
+                    part = merge(part);
+                }
+                unsigned nw = node[bb];
+                unsigned nw1 = node[(nrows > 1 ? 1 : 0) * B + bb];
+                for (int a = a0; a < a_end; a++) {
+                    const int i = a - a0;
+                    const int i2 = i + 2 < nrows ? i + 2 : nrows - 1;  // (past the chunk: re-read its last row, unused)
+                    const int s01 = (nw >> 2) & 127, s10 = (nw >> 9) & 127;
+                    const double p01 = __shfl(cur, gbase + (s01 < B ? s01 : bb), SVX_WAVE);
+                    const double p10 = __shfl(cur, gbase + (s10 < B ? s10 : bb), SVX_WAVE);
+                    double pv[DPF_TPL];
+                    int sl2[DPF_TPL];
+                    float cs2[DPF_TPL];
+#pragma unroll
+                    for (int j = 0; j < DPF_TPL; j++) {
+                        pv[j] = ring[sl1[j]];
+                        const int o = i2 * TB + toff[j];
+                        sl2[j] = tval[j] ? (int)idx[o] : RD * B;
+                        cs2[j] = cost[o];
+                    }
+                    const unsigned nw2 = node[i2 * B + bb];
+                    cur = finish(a, i, nw, part, p01, p10);
+                    Part np{inf, 0x7fffffff};
+#pragma unroll
+                    for (int j = 0; j < DPF_TPL; j++) {
+                        const double tot = pv[j] + (double)cs1[j];
+                        if (tot < np.tot) { np.tot = tot; np.key = tkey[j]; }
+                    }
+                    part = merge(np);
+#pragma unroll
+                    for (int j = 0; j < DPF_TPL; j++) { sl1[j] = sl2[j]; cs1[j] = cs2[j]; }
+                    nw = nw1;
+                    nw1 = nw2;
+                    slot = (slot + 1 == RD) ? 0 : slot + 1;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+                Part part = T > 0 ? partial(0) : Part{inf, 0x7fffffff};
+                unsigned nw = node[bb];
+                for (int a = a0; a < a_end; a++) {
+                    const int i = a - a0;
+                    const int inext = a + 1 < a_end ? i + 1 : i;  // (the last diagonal re-reads itself: no branch)
+                    const unsigned nnw = node[inext * B + bb];
+                    Part npart{inf, 0x7fffffff};
+                    if (T > 0) npart = partial(inext);
+                    const int s01 = (nw >> 2) & 127, s10 = (nw >> 9) & 127;
+                    const double p01 = __shfl(cur, gbase + (s01 < B ? s01 : bb), SVX_WAVE);
+                    const double p10 = __shfl(cur, gbase + (s10 < B ? s10 : bb), SVX_WAVE);
+                    cur = finish(a, i, nw, part, p01, p10);
+                    part = npart;
+                    nw = nnw;
+                    slot = (slot + 1 == RD) ? 0 : slot + 1;
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
         __syncthreads();
