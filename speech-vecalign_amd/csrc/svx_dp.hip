@@ -442,43 +442,6 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
             const int a_end = (a0 + CH) < Aout ? (a0 + CH) : Aout;
             const int TB = T * B;
             struct Part { double tot; int key; };
-            // the type moves of node diagonal a0 + i: this lane's candidates, then the merge across lane groups
-            auto partial = [&](int i) {
-                Part r{inf, 0x7fffffff};
-                if (unrolled) {
-                    double pv[DPF_TPL];
-                    float cs[DPF_TPL];
-#pragma unroll
-                    for (int j = 0; j < DPF_TPL; j++) {
-                        const int o = i * TB + toff[j];
-                        const int sl = tval[j] ? (int)idx[o] : RD * B;
-                        cs[j] = cost[o];
-                        pv[j] = ring[sl];
-                    }
-#pragma unroll
-                    for (int j = 0; j < DPF_TPL; j++) {
-                        const double tot = pv[j] + (double)cs[j];
-                        if (tot < r.tot) { r.tot = tot; r.key = tkey[j]; }
-                    }
-                } else {
-                    for (int t = grp; t < T; t += G) {
-                        const int o = i * TB + t * B + bb;
-                        const double tot = ring[idx[o]] + (double)cost[o];
-                        if (tot < r.tot) { r.tot = tot; r.key = (t << 16) | (tpk[t] & 0xffff); }
-                    }
-                }
-                if (G == 4) {
-                    const double ob = xchg16_f64(r.tot, lane);
-                    const int ok2 = (int)xchg16_u32((unsigned)r.key, lane);
-                    if (ob < r.tot || (ob == r.tot && ok2 < r.key)) { r.tot = ob; r.key = ok2; }
-                }
-                if (G >= 2) {
-                    const double ob = xchg32_f64(r.tot, lane);
-                    const int ok2 = (int)xchg32_u32((unsigned)r.key, lane);
-                    if (ob < r.tot || (ob == r.tot && ok2 < r.key)) { r.tot = ob; r.key = ok2; }
-                }
-                return r;
-            };
             // group merge of one lane's best type move (shared by both sweeps below)
             auto merge = [&](Part r) {
                 if (G == 4) {
@@ -492,6 +455,16 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
                     if (ob < r.tot || (ob == r.tot && ok2 < r.key)) { r.tot = ob; r.key = ok2; }
                 }
                 return r;
+            };
+            // the type moves of node diagonal a0 + i (generic type count): this lane's candidates, merged across groups
+            auto partial = [&](int i) {
+                Part r{inf, 0x7fffffff};
+                for (int t = grp; t < T; t += G) {
+                    const int o = i * TB + t * B + bb;
+                    const double tot = ring[idx[o]] + (double)cost[o];
+                    if (tot < r.tot) { r.tot = tot; r.key = (t << 16) | (tpk[t] & 0xffff); }
+                }
+                return merge(r);
             };
             // stage 2 of diagonal a: the deletions, from the register copy of diagonal a-1 (p01 / p10), then the
             // node's border / outside cases; stores the node and returns its csum
