@@ -381,6 +381,32 @@ __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restric
     }
 }
 
+// Documents too long for the sort's LDS histogram (> ~38 000 segments): the samples are scored in their drawn
+// order, one wave per sample (both rows fetched per sample; slower, no size limit).
+template <typename E, int NCH, bool LV0>
+__global__ __launch_bounds__(256) void k_knob_scores_unsorted(const SvxPairDev* __restrict__ pairs) {
+    const SvxPairDev& P = pairs[blockIdx.z];
+    const int level = (int)blockIdx.y + (LV0 ? 0 : 1);
+    if (level > P.L) return;
+    if (!LV0 && level == P.L) return;  // (k_knob_from_dots)
+    const SvxLevel& Lv = P.lev[level];
+    ScoreArgs g;
+    g.v1 = LV0 ? P.v[0] : (const void*)Lv.P[0];
+    g.v2 = LV0 ? P.v[1] : (const void*)Lv.P[1];
+    g.inv1 = LV0 ? Lv.inv[0] : nullptr;
+    g.inv2 = LV0 ? Lv.inv[1] : nullptr;
+    g.n1 = Lv.nrm[0];
+    g.n2 = Lv.nrm[1];
+    g.xx = Lv.kx;
+    g.yy = Lv.ky;
+    g.n = Lv.kn;
+    g.rows1 = Lv.n[0];
+    g.rows2 = Lv.n[1];
+    g.d = P.d;
+    g.out = Lv.kscore;
+    score_block<E, NCH>(g, (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), (int64_t)gridDim.x * 4);
+}
+
 // Sampled scores of the coarsest level (L >= 1): score_path (dp_core.pyx:143-161) from the dot products that the
 // dense cost stage of the same level has just computed on the matrix cores -- no row is read again.
 __global__ __launch_bounds__(256) void k_knob_from_dots(const SvxPairDev* __restrict__ pairs) {
@@ -839,9 +865,48 @@ int svxl_knob_scores(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int max
                      int part) {
     if (n_pairs <= 0 || max_kn <= 0) return SVX_OK;
     hipStream_t st = ctx->stream;
+    const bool unsorted = (size_t)(max_n0 + 1) * sizeof(int) > 150 * 1024;  // the sort's histogram does not fit LDS
+    if (unsorted) {
+        if (part == 0) return SVX_OK;
+        const int nbu = (max_kn + 3) / 4 < 2048 ? (max_kn + 3) / 4 : 2048;
+#define U32(N, LV0, GY) hipLaunchKernelGGL((k_knob_scores_unsorted<ElemF32, N, LV0>), dim3(nbu, GY, n_pairs), dim3(256), 0, st, pairs)
+#define U16(E, N) hipLaunchKernelGGL((k_knob_scores_unsorted<E, N, true>), dim3(nbu, 1, n_pairs), dim3(256), 0, st, pairs)
+        if (part == 1) {
+            if (max_L >= 1) {
+                switch (nch_f32(d)) {
+                    case 1: U32(1, false, max_L); break;
+                    case 2: U32(2, false, max_L); break;
+                    case 4: U32(4, false, max_L); break;
+                    default: U32(8, false, max_L); break;
+                }
+            }
+        } else if (dtype == SVX_F32) {
+            switch (nch_f32(d)) {
+                case 1: U32(1, true, 1); break;
+                case 2: U32(2, true, 1); break;
+                case 4: U32(4, true, 1); break;
+                default: U32(8, true, 1); break;
+            }
+        } else if (dtype == SVX_F16) {
+            switch (nch_16(d)) {
+                case 1: U16(ElemF16, 1); break;
+                case 2: U16(ElemF16, 2); break;
+                default: U16(ElemF16, 4); break;
+            }
+        } else {
+            switch (nch_16(d)) {
+                case 1: U16(ElemBF16, 1); break;
+                case 2: U16(ElemBF16, 2); break;
+                default: U16(ElemBF16, 4); break;
+            }
+        }
+#undef U32
+#undef U16
+        SVX_LAUNCH_CHECK(ctx, "k_knob_scores_unsorted");
+        return SVX_OK;
+    }
     if (part == 0) {
         const size_t smem = (size_t)(max_n0 + 1) * sizeof(int);
-        if (smem > 150 * 1024) return svx_fail(ctx, SVX_ERR_ARG, "knob sort: %d source rows exceed the LDS histogram", max_n0);
         if (smem > 64 * 1024)
             SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_knob_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(k_knob_sort, dim3(max_L + 1, n_pairs), dim3(256), smem, st, pairs);

@@ -245,3 +245,18 @@ def test_randomised_sweep_small():
     bad, ties, edges = run_sweep(160, 11, verbose=False)
     assert bad == 0
     assert ties + edges <= 3
+
+
+def test_document_longer_than_the_sort_histogram(orc):
+    """More than ~38 000 segments per side: the sampled-score pass cannot sort by source row in LDS and scores the
+    samples in drawn order instead (k_knob_scores_unsorted); everything else is size-independent.  Against the oracle."""
+    from svx.vecalign import dp_utils
+    N, M, K, d = 40000, 39000, 2, 32
+    v0, v1 = make_pair(N, M, K, d, 123, deletions=40)
+    types = alignment_types(3)
+    np.random.seed(9)
+    ref = orc.vecalign(v0.copy(), v1.copy(), types, 0.2, 6, 300, 20000, 100)
+    np.random.seed(9)
+    got = dp_utils.vecalign(v0, v1, types, 0.2, 6, 300, 20000, 100)
+    assert got[0]['final_alignments'] == ref[0]['final_alignments']
+    assert np.abs(got[0]['alignment_scores'] - ref[0]['alignment_scores']).max() < SCORE_TOL
