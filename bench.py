@@ -101,6 +101,18 @@ def main():
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     esz = 4 if args.dtype == "f32" else 2
     P = args.pairs
+    # Keep the step inside this GPU's free memory: a pair needs its inputs plus the scratch arena (measured 95 MB for
+    # the 67 MB of bf16 inputs of the default workload); every rank uses the smallest count any rank can hold.
+    free_b, _total_b = torch.cuda.mem_get_info(dev)
+    per_pair = K * (N + M) * d * esz + int(1.6 * K * (N + M) * d * 2) + (8 << 20)
+    fit = max(1, int(0.92 * free_b) // per_pair)
+    if dist is not None:
+        tf = torch.tensor([fit], device=dev, dtype=torch.int64)
+        dist.all_reduce(tf, op=dist.ReduceOp.MIN)
+        fit = int(tf.item())
+    if fit < P:
+        print("bench: %d pairs per step do not fit the free HBM (%.0f GB); using %d" % (P, free_b / 1e9, fit), file=sys.stderr)
+        P = fit
     docs = [synth_pair_device(N, M, K, d, 1000 * rank + i, dev, tdt) for i in range(P)]
     rngs = [np.random.RandomState(np.random.SeedSequence([2024, rank, i]).generate_state(4)) for i in range(P)]
     pb = dp_utils.PreparedBatch(docs, types, 0.2, W, 300, 20000, 100, rngs=rngs, device=local)
@@ -152,7 +164,7 @@ def main():
         "config": {"workload": "synthetic %dx%d d=%d %s embeddings, %d overlap layers/side, %d alignment types, band %d, "
                                "coarse-to-fine (max_size_full_dp=300), %d doc-pairs per GPU per step" %
                                (N, M, d, args.dtype, K, len(types), 2 * W, P),
-                   "pairs_per_step_per_gpu": P, "streams": args.streams, "N": N, "M": M, "d": d, "overlaps": K, "parallelism": "dp%d (pairs sharded, no collective)" % world},
+                   "pairs_per_step_per_gpu": P, "pairs_per_step_requested": args.pairs, "streams": args.streams, "N": N, "M": M, "d": d, "overlaps": K, "parallelism": "dp%d (pairs sharded, no collective)" % world},
         "dp_cells_per_s": value * cells, "dp_cells_per_pair": cells,
         "hbm_bytes_resident": {"inputs": int(sum(a.numel() * a.element_size() + b.numel() * b.element_size() for a, b in docs)),
                                "scratch_arena": int(lib.svx_scratch_bytes(ctx.h))},
