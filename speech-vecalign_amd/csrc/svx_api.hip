@@ -637,7 +637,9 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             const SvxTypes& ty = depth == 0 ? tfinal : t11;
             {
                 StageScope sc(ctx, S_PATH);
-                if ((rc2 = svxl_search_path_batch(ctx, dp, np, depth, max_A[depth]))) return rc2;
+                // (pairs whose source level has more alignment rows than the LDS holds take the kernel's serial path)
+                const int src_rows = (maxL > 0 && !any_L0) ? max_A[depth] / 2 + 8 : max_A[depth];
+                if ((rc2 = svxl_search_path_batch(ctx, dp, np, depth, max_A[depth], src_rows))) return rc2;
             }
             {
                 StageScope sc(ctx, depth == 0 ? S_BAND_COSTS0 : S_BAND_COSTSN);
@@ -654,7 +656,6 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         }
         return SVX_OK;
     };
-    (void)any_L0;
     {
         StageScope total(ctx, S_TOTAL);
         {

@@ -218,6 +218,6 @@ int svxl_sparse_traceback(svx_ctx*, const double* csum, const int* xp, const int
 int svxl_sparse_traceback_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int B, int max_A, int packed);
 int svxl_search_path(svx_ctx*, const int* align, const int* n_align, int upsample, int size0, int size1, int* path,
                      int cap, int* path_len);
-int svxl_search_path_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int max_rows);
+int svxl_search_path_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int max_rows, int max_src_rows);
 int svxl_del_penalty(svx_ctx*, const float* scores, int64_t n, double frac, double* out);
 int svxl_del_penalty_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_levels, double frac);

@@ -1346,10 +1346,12 @@ int svxl_search_path(svx_ctx* ctx, const int* align, const int* n_align, int ups
     return SVX_OK;
 }
 
-int svxl_search_path_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int depth, int max_rows) {
+// max_rows: path capacity of the longest pair at this depth; max_src_rows: alignment rows of the level the path is
+// built from (half as many when it is the up-sampled coarser level) -- what the path kernel keeps in LDS.
+int svxl_search_path_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int depth, int max_rows, int max_src_rows) {
     if (n_pairs <= 0) return SVX_OK;
     size_t smem;
-    const int rows = sp_lds_rows(max_rows, &smem);
+    const int rows = sp_lds_rows(max_src_rows, &smem);
     if (smem > 64 * 1024)
         SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_search_path_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(k_search_path_batch, dim3(n_pairs), dim3(256), smem, ctx->stream, pairs, depth, rows);
