@@ -388,8 +388,17 @@ __global__ __launch_bounds__(256) void k_colmean(const SvxPairDev* __restrict__ 
     const SvxLevel& Lv = P.lev[level];
     const int np = Lv.npart[side];
     const float* part = Lv.part[side] + (size_t)k * np * P.d;
+    // (same left-to-right order of additions as a plain loop; the loads of eight partials are in flight together)
     float s = 0.f;
-    for (int b = 0; b < np; b++) s += part[(size_t)b * P.d + c];
+    int b = 0;
+    for (; b + 8 <= np; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = part[(size_t)(b + u) * P.d + c];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; b < np; b++) s += part[(size_t)b * P.d + c];
     Lv.mean[side][(size_t)k * P.d + c] = s / (float)Lv.n[side];
 }
 
