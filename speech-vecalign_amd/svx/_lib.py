@@ -157,7 +157,14 @@ class Context:
 _ctxs = {}
 
 
-def context(device=0):
+def context(device=None):
+    """The svx context of `device` (default: torch's current device, so that a process that called
+    torch.cuda.set_device(LOCAL_RANK) works on its own GPU without passing the index around)."""
+    if device is None:
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("svx needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+        device = torch.cuda.current_device()
     device = int(device)
     if device not in _ctxs:
         _ctxs[device] = Context(device)

@@ -77,7 +77,7 @@ class FlatIndex:
     """Unit-norm rows [ntotal, d] in fp16 (default) or bf16 on one GPU."""
 
     def __init__(self, d: int = 1024, storage: str = "fp16", device=None):
-        self.ctx = _lib.context(0 if device is None else device)
+        self.ctx = _lib.context(device)
         t = self.ctx.torch
         if storage not in ("fp16", "bf16"):
             raise ValueError(f"storage {storage!r}: the database is kept in fp16 or bf16")

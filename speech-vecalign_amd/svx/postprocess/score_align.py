@@ -87,7 +87,7 @@ def global_margin_scores(x_local, y_local, k: int = 16, margin: str = "ratio", s
                          device=None):
     """Each rank passes the embeddings of ITS alignments; the databases are the union over ranks
     (all-gather of the normalised fp16 rows), the scores come back for the local rows only."""
-    ctx = _lib.context(0 if device is None else device)
+    ctx = _lib.context(device)
     d = int(x_local.shape[1])
     idx_x, idx_y = FlatIndex(d, storage, device), FlatIndex(d, storage, device)
     idx_x.add(x_local)

@@ -105,7 +105,7 @@ def gather_candidates(line_embeddings, table: np.ndarray, device=None):
     """Device gather (svx_gather_rows): out[j, i] = line_embeddings[table[j, i]] or 0 -> torch tensor [K, N, d]."""
     import ctypes
     from .. import _lib
-    ctx = _lib.context(0 if device is None else device)
+    ctx = _lib.context(device)
     t = ctx.torch
     # (np.array copies: the file readers hand out read-only memory maps)
     emb = line_embeddings if hasattr(line_embeddings, "data_ptr") else t.from_numpy(np.array(line_embeddings))

@@ -113,7 +113,7 @@ class PreparedBatch:
 
     def __init__(self, pairs, final_alignment_types, del_percentile_frac, width_over2, max_size_full_dp,
                  costs_sample_size, num_samps_for_norm, rngs=None, norms=None, device=None):
-        ctx = _lib.context(0 if device is None else device)
+        ctx = _lib.context(device)
         self.ctx = ctx
         t = ctx.torch
         if width_over2 < 3:

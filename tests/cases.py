@@ -18,6 +18,7 @@ PIPELINE_CASES = {
     "zero_rows":      dict(N=500, M=480, a=5, d=64, seed=8, rng_seed=9, zero_rows=25),   # PAD / ignored candidates: exact cost ties
     "deletions":      dict(N=600, M=560, a=5, d=64, seed=9, rng_seed=10, deletions=30),
     "fp16_d1024":     dict(N=512, M=512, a=5, d=1024, seed=10, rng_seed=11, dtype="f16"),
+    "f32_d1024":      dict(N=512, M=512, a=6, d=1024, seed=15, rng_seed=16),                # BASELINE configs[0]: 512 x 512, d = 1024, float32 storage, -a 6
     "bf16_d1024":     dict(N=640, M=600, a=5, d=1024, seed=11, rng_seed=12, dtype="bf16"),
     "frac_quarter":   dict(N=420, M=400, a=4, d=64, seed=12, rng_seed=13, frac=0.25),   # knot 7/28 exactly
     "small_full_dp":  dict(N=420, M=400, a=4, d=64, seed=13, rng_seed=14, max_full=50),  # deeper pyramid (L = 4)

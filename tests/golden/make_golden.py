@@ -135,6 +135,42 @@ def gen_example(ref):
     print("example_trim:", sum(os.path.getsize(os.path.join(od, f)) for f in os.listdir(od)) // 1024, "KiB")
 
 
+def gen_example_full(ref):
+    """The reference's whole shipped example as data (tests/golden/example_full): segments, candidate lines,
+    ignore files, the two .embed payloads as raw fp16 (the shipped files are .npy v1.0 '<f2'), the shipped
+    156-line alignment file and the gold alignment -- plus the REAL reference's own output on these files
+    for np.random.seed(0 / 1 / 42) (its scores depend on the unseeded global stream; its spans do not)."""
+    import shutil
+    ex = os.path.join(ref.root, "example", "voxpopuli")
+    stem = "20180313-0900-PLENARY-15"
+    od = os.path.join(HERE, "example_full")
+    os.makedirs(od, exist_ok=True)
+    for lang in ("en", "de"):
+        shutil.copyfile(os.path.join(ex, "segments", lang, f"{stem}_{lang}.txt"), os.path.join(od, f"segments_{lang}.txt"))
+        shutil.copyfile(os.path.join(ex, "cat_segs", lang, f"{stem}_{lang}.txt"), os.path.join(od, f"cat_segs_{lang}.txt"))
+        emb = np.load(os.path.join(ex, "embeds", lang, f"{stem}_{lang}.embed"), allow_pickle=False)
+        assert emb.dtype == np.float16 and emb.shape[1] == 1024
+        np.ascontiguousarray(emb).tofile(os.path.join(od, f"embeds_{lang}.f16"))
+    for side in ("src", "tgt"):
+        shutil.copyfile(os.path.join(ex, "untrans_cat_seg_ids", "en-de", f"{stem}_en-{stem}_de.{side}.txt"),
+                        os.path.join(od, f"ignore_{side}.txt"))
+    shutil.copyfile(os.path.join(ex, "alignments", "en-de", f"{stem}_en-{stem}_de.txt"), os.path.join(od, "shipped_alignment.txt"))
+    shutil.copyfile(os.path.join(ex, f"{stem}.gold"), os.path.join(od, "gold.txt"))
+    for f in os.listdir(od):
+        os.chmod(os.path.join(od, f), 0o644)
+    for seed in (0, 1, 42):
+        np.random.seed(seed)
+        ref.vecalign.align(src=os.path.join(od, "segments_en.txt"), tgt=os.path.join(od, "segments_de.txt"),
+                           src_embed=[os.path.join(od, "cat_segs_en.txt"), os.path.join(od, "embeds_en.f16")], src_stopes=False,
+                           src_fp16=True, tgt_embed=[os.path.join(od, "cat_segs_de.txt"), os.path.join(od, "embeds_de.f16")],
+                           tgt_stopes=False, tgt_fp16=True, alignment_max_size=6, many_to_one=None, search_buffer_size=5,
+                           del_percentile_frac=0.2, max_size_full_dp=300, costs_sample_size=20000, num_samps_for_norm=100,
+                           overlap_segments=True, print_aligned_text=False, print_results=True,
+                           save_aligned_text_to_file=os.path.join(od, "expected_seed%d.txt" % seed),
+                           src_ignore_indices=os.path.join(od, "ignore_src.txt"), tgt_ignore_indices=os.path.join(od, "ignore_tgt.txt"))
+    print("example_full:", sum(os.path.getsize(os.path.join(od, f)) for f in os.listdir(od)) // 1024, "KiB")
+
+
 def gen_margin(ref_root):
     """The reference's shipped margin-scoring example as data: the rows of its two populated Flat indexes
     (exactly fp16-representable, stored as fp16) and the third field of its margin file.  The aligned
@@ -180,7 +216,7 @@ def gen_post(ref_root):
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["ops", "pipeline", "example", "margin", "post"]
+    what = sys.argv[1:] or ["ops", "pipeline", "example", "example_full", "margin", "post"]
     if "post" in what:
         gen_post(ref_loader.REF_ROOT)
     if "margin" in what:
@@ -193,3 +229,5 @@ if __name__ == "__main__":
             gen_pipeline(ref)
         if "example" in what:
             gen_example(ref)
+        if "example_full" in what:
+            gen_example_full(ref)

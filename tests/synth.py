@@ -42,3 +42,24 @@ def round_bf16(a):
 def alignment_types(a):
     """vecalign.py:154-162 order"""
     return [(x, y) for x in range(1, a) for y in range(1, a) if x + y <= a]
+
+
+def make_pair_device(N, M, K, d, seed, device, dtype):
+    """make_pair's layout generated on the GPU (torch), for batches too large to build on the host:
+    layer k row i = sum of base rows i-k..i (rows i < k zero); target = noisy copy of the source.
+    Returns torch tensors [K][N][d], [K][M][d] of `dtype`."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    L = max(N, M)
+    base = torch.randn((L, d), generator=g, device=device, dtype=torch.float32)
+    tgt = base + 0.5 * torch.randn((L, d), generator=g, device=device, dtype=torch.float32)
+
+    def layers(b, n):
+        cs = torch.cat([torch.zeros((1, d), device=device, dtype=torch.float64), torch.cumsum(b[:n].double(), 0)])
+        out = torch.zeros((K, n, d), device=device, dtype=torch.float32)
+        for k in range(K):
+            out[k, k:] = (cs[k + 1:n + 1] - cs[:n - k]).float()
+        return out.to(dtype).contiguous()
+
+    return layers(base, N), layers(tgt, M)

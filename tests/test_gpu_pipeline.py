@@ -237,6 +237,32 @@ def test_ragged_batch_up_to_8192(orc):
     assert res[i][0] == ref[0]['final_alignments'] and np.abs(res[i][1] - ref[0]['alignment_scores']).max() < SCORE_TOL
 
 
+def test_ragged_batch_c3_scale(orc):
+    """BASELINE configs[2] at scale on one GPU: 256 document pairs, N, M ~ U{512..8192} i.i.d. (seed 1), d = 1024,
+    bf16, 4 overlap layers (10 types, band 14), one svx_align_batch call.  Every pair: full monotone coverage
+    of both documents (a size-independent property of any valid alignment); three pairs (the largest, the
+    smallest and a random one) against the CPU oracle on the same rounded inputs and the same sampled indices."""
+    import torch
+    from synth import make_pair_device
+    from svx.vecalign import dp_utils
+    rs = np.random.RandomState(1)
+    shapes = [(int(rs.randint(512, 8193)), int(rs.randint(512, 8193))) for _ in range(256)]
+    types = alignment_types(5)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    docs = [make_pair_device(n, m, 4, 1024, 7000 + i, dev, torch.bfloat16) for i, (n, m) in enumerate(shapes)]
+    res = dp_utils.align_batch(docs, types, 0.2, 7, 300, 20000, 100, rngs=[np.random.RandomState(900 + i) for i in range(len(docs))])
+    for (n, m), r in zip(shapes, res):
+        assert [x for al in r[0] for x in al[0]] == list(range(n)) and [y for al in r[0] for y in al[1]] == list(range(m))
+        assert np.isfinite(r[1]).all() and (r[1] >= 0).all()
+    sizes = [n + m for n, m in shapes]
+    picks = {int(np.argmax(sizes)), int(np.argmin(sizes)), int(rs.randint(0, 256))}
+    for i in sorted(picks):
+        h0, h1 = docs[i][0].float().cpu().numpy(), docs[i][1].float().cpu().numpy()
+        ref = orc.vecalign(h0, h1, types, 0.2, 7, 300, 20000, 100, rng=np.random.RandomState(900 + i))
+        assert res[i][0] == ref[0]['final_alignments'], shapes[i]
+        assert np.abs(res[i][1] - ref[0]['alignment_scores']).max() < SCORE_TOL
+
+
 def test_randomised_sweep_small():
     """A short run of tests/fuzz_gpu_vs_oracle.py (random sizes, layers, types, band widths, thresholds, storage
     types, deletions, zero rows; ragged batches): identical spans and scores within 1e-4 in every case that is not an
@@ -260,3 +286,24 @@ def test_document_longer_than_the_sort_histogram(orc):
     got = dp_utils.vecalign(v0, v1, types, 0.2, 6, 300, 20000, 100)
     assert got[0]['final_alignments'] == ref[0]['final_alignments']
     assert np.abs(got[0]['alignment_scores'] - ref[0]['alignment_scores']).max() < SCORE_TOL
+
+
+def test_context_follows_current_device():
+    """A rank that called torch.cuda.set_device(LOCAL_RANK) must compute on that GPU (seg_align.align under
+    torchrun): contexts default to torch's current device.  Needs two visible devices for the non-trivial half."""
+    import torch
+    from svx import _lib
+    from svx.vecalign import dp_utils
+    cur = torch.cuda.current_device()
+    assert _lib.context().device == cur
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device: only the default-device half can be checked")
+    try:
+        torch.cuda.set_device(1)
+        pb = dp_utils.PreparedBatch([make_pair(300, 280, 3, 64, 5)], alignment_types(4), 0.2, 7, 300, 20000, 100,
+                                    rngs=[np.random.RandomState(1)])
+        assert pb.ctx.device == 1 and pb.align.device.index == 1 and pb.vecs[0][0].device.index == 1
+        pb.run()
+        assert len(pb.results()[0][0]) > 0
+    finally:
+        torch.cuda.set_device(cur)
