@@ -123,10 +123,43 @@ int svx_search_path(svx_ctx *ctx, const int32_t *align, const int32_t *n_align, 
                     int size1, int32_t *path, int32_t *path_len);
 
 /* make_doc_embedding's gather (svecalign/utils/embedding_utils.py:164-201): out[r][:] = table[idx[r]][:],
- * or zeros where idx[r] < 0 (PAD / ignored / missing / NaN candidate).  table [n_rows][d], out [n_out][d]
- * of `dtype`; idx [n_out] int32 is the flattened [overlaps][segments] row table built on the host. */
+ * or zeros where idx[r] < 0 (PAD / ignored / missing candidate) or where the source row holds a NaN
+ * (embedding_utils.py:183-190).  table [n_rows][d], out [n_out][d] of `dtype`; idx [n_out] int32 is the
+ * flattened [overlaps][segments] row table (svx_candidate_table, or the Python mirror of make_overlap). */
 int svx_gather_rows(svx_ctx *ctx, const void *table, int64_t n_rows, int d, int dtype, const int32_t *idx, int64_t n_out,
                     void *out);
+
+/* ---- host-side helpers (HOST pointers, no device work, callable from any thread) ---------
+ * What a driver needs besides the kernels to keep a GPU fed: the random row indices, the candidate index
+ * table of a document and the text of an alignment file. */
+
+/* np.random.RandomState.choice(n, size, replace=True) (the call of dp_utils.py:301-302,346), bit for bit: MT19937
+ * 32-bit outputs with masked rejection.  key[624] / *pos are RandomState.get_state()[1] / [2], advanced in place. */
+int svx_mt19937_choice(uint32_t *key, int32_t *pos, int64_t n, int64_t size, int32_t *out);
+
+/* Lengths of svx_pair.norm_idx / svx_pair.knob_idx for a pair of these sizes. */
+int64_t svx_norm_index_count(int n, int m, int k0, int k1, int max_size_full_dp, int num_samps_for_norm, int have_norms0,
+                             int have_norms1);
+int64_t svx_knob_index_count(int n, int m, int max_size_full_dp, int costs_sample_size);
+
+/* All random row indices of one vecalign() call, in the reference's draw order (dp_utils.py:423-444 then
+ * :450-456), laid out as svx_pair.norm_idx / knob_idx document.  have_norms0/1: the depth-0
+ * normalisers of that side are given (dp_utils.py:428-444), so its draws are skipped. */
+int svx_draw_indices(uint32_t *key, int32_t *pos, int n, int m, int k0, int k1, int max_size_full_dp, int costs_sample_size,
+                     int num_samps_for_norm, int have_norms0, int have_norms1, int32_t *norm_idx, int32_t *knob_idx);
+
+/* make_doc_embedding's table for speech segments (overlap_segments=True; embedding_utils.py:106-132, 164-201,
+ * read_in_embeddings :93-99, load_ignore_index_file vecalign.py:187-195): table[o][i] = first line of `cat_path`
+ * equal to "<start of segment i-o> <end of segment i>", or -1 (slot i < o, ignored from that overlap on, or no
+ * such candidate).  table [max_overlaps][cap_lines] (NULL: only *n_lines / *n_candidates are returned).
+ * ignore_path may be NULL.  err: optional message buffer. */
+int svx_candidate_table(const char *seg_path, const char *cat_path, const char *ignore_path, int max_overlaps, int32_t *table,
+                        int cap_lines, int32_t *n_lines, int64_t *n_candidates, char *err, int err_cap);
+
+/* print_alignments (vecalign.py:174-184): "[x ids]:[y ids]:%.6f\n" per row (x_start, x_len, y_start, y_len), Python
+ * list syntax; scores may be NULL ("[..]:[..]\n").  Returns the number of bytes needed; they are written to out
+ * when they fit in cap. */
+int64_t svx_format_alignments(const int32_t *rows, const double *scores, int64_t n, char *out, int64_t cap);
 
 /* ---- global margin scoring of the mined alignments (next row after the alignment path) ---
  * svecalign/postprocess/score_align.py:118-161 (compute_sim_with_nonflat_idx) and the index side of

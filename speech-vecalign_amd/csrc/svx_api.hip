@@ -359,7 +359,7 @@ int svx_gather_rows(svx_ctx* ctx, const void* table, int64_t n_rows, int d, int 
     NEED(ctx, dtype == SVX_F32 || dtype == SVX_F16 || dtype == SVX_BF16, "svx_gather_rows: unknown dtype %d", dtype);
     int rc = check_dim(ctx, d);
     if (rc) return rc;
-    return svxl_gather_rows(ctx, table, n_rows, d * (dtype == SVX_F32 ? 4 : 2), idx, n_out, out);
+    return svxl_gather_rows(ctx, table, n_rows, d * (dtype == SVX_F32 ? 4 : 2), dtype, idx, n_out, out);
 }
 
 int svx_num_levels(int n, int m, int max_size_full_dp) {

@@ -189,7 +189,7 @@ int svxl_colmean_plain(svx_ctx*, const float* part, int k, int nblk, int d, int 
 int svxl_sub_mean(svx_ctx*, float* half, int k, int h, int d, const float* mean);
 int svxl_sample_mean_plain(svx_ctx*, const float* vecs, int k, int n, int d, const int* idx, int S, float* rbar);
 int svxl_norms_from_rbar(svx_ctx*, const float* vecs, int64_t rows, int d, const float* rbar, float* norms);
-int svxl_gather_rows(svx_ctx*, const void* table, long long n_rows, int row_bytes, const int* idx, long long n_out, void* out);
+int svxl_gather_rows(svx_ctx*, const void* table, long long n_rows, int row_bytes, int dtype, const int* idx, long long n_out, void* out);
 int svxl_pyramid_level(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int level, int dtype, int d, int max_nblk,
                        int max_ksum, int part);
 // costs (svx_costs.hip)

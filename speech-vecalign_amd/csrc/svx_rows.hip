@@ -527,17 +527,51 @@ __global__ __launch_bounds__(256) void k_rownorms_plain(const float* vecs, int64
 }
 
 // Candidate-tensor assembly (svecalign/utils/embedding_utils.py:135-203): out[r] = table[idx[r]], or an
-// all-zero row where idx[r] < 0 (PAD / ignored / missing / NaN candidate).  16 bytes per lane.
+// all-zero row where idx[r] < 0 (PAD / ignored / missing candidate) or where the source row holds a NaN
+// (embedding_utils.py:183-190: "loaded a vector with nan value ... Will reset to zero").  One wave per output
+// row: its 16-byte pieces sit in registers while the wave votes on the NaN test, then the row is stored.
+// DT: 0 float32, 1 float16, 2 bfloat16 (which bit patterns are NaNs); PPL = pieces per lane.
+template <int DT>
+__device__ __forceinline__ bool piece_has_nan(const uint4& v) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (DT == SVX_F32) {
+            bad |= (w[i] & 0x7fffffffu) > 0x7f800000u;
+        } else {
+            const uint32_t lim = DT == SVX_F16 ? 0x7c00u : 0x7f80u;
+            bad |= (w[i] & 0x7fffu) > lim;
+            bad |= ((w[i] >> 16) & 0x7fffu) > lim;
+        }
+    }
+    return bad;
+}
+
+template <int DT, int PPL>
 __global__ __launch_bounds__(256) void k_gather_rows(const uint4* __restrict__ table, const int* __restrict__ idx, long long n_out,
                                                      int row_pieces, long long n_rows, uint4* __restrict__ out) {
-    const long long total = n_out * row_pieces;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long r = i / row_pieces;
-        const int p = (int)(i - r * row_pieces);
+    const int lane = threadIdx.x & 63;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_out; r += (long long)gridDim.x * 4) {
         const int src = idx[r];
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (src >= 0 && src < n_rows) v = table[(long long)src * row_pieces + p];
-        out[i] = v;
+        const bool have = src >= 0 && src < n_rows;  // wave-uniform
+        uint4 v[PPL];
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            const int p = lane + 64 * i;
+            v[i] = make_uint4(0, 0, 0, 0);
+            if (have && p < row_pieces) {
+                v[i] = table[(long long)src * row_pieces + p];
+                bad |= piece_has_nan<DT>(v[i]);
+            }
+        }
+        const bool zero = __ballot(bad) != 0ull;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            const int p = lane + 64 * i;
+            if (p < row_pieces) out[r * row_pieces + p] = zero ? make_uint4(0, 0, 0, 0) : v[i];
+        }
     }
 }
 
@@ -659,13 +693,28 @@ int svxl_pyramid_level(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int l
     return SVX_OK;
 }
 
-int svxl_gather_rows(svx_ctx* ctx, const void* table, long long n_rows, int row_bytes, const int* idx, long long n_out, void* out) {
+int svxl_gather_rows(svx_ctx* ctx, const void* table, long long n_rows, int row_bytes, int dtype, const int* idx, long long n_out,
+                     void* out) {
     if (n_out <= 0) return SVX_OK;
     const int pieces = row_bytes / 16;
-    long long nb = (n_out * pieces + 255) / 256;
+    long long nb = (n_out + 3) / 4;
     if (nb > 65535) nb = 65535;
-    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)nb), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4*>(table), idx, n_out,
-                       pieces, n_rows, reinterpret_cast<uint4*>(out));
+    const int ppl = (pieces + 63) / 64;
+    const uint4* t4 = reinterpret_cast<const uint4*>(table);
+    uint4* o4 = reinterpret_cast<uint4*>(out);
+#define G(DT, PPL) hipLaunchKernelGGL((k_gather_rows<DT, PPL>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, t4, idx, n_out, pieces, n_rows, o4)
+#define GP(DT)                                 \
+    do {                                       \
+        if (ppl <= 1) G(DT, 1);                \
+        else if (ppl <= 2) G(DT, 2);           \
+        else if (ppl <= 4) G(DT, 4);           \
+        else G(DT, 8);                         \
+    } while (0)
+    if (dtype == SVX_F32) GP(SVX_F32);
+    else if (dtype == SVX_F16) GP(SVX_F16);
+    else GP(SVX_BF16);
+#undef GP
+#undef G
     SVX_LAUNCH_CHECK(ctx, "k_gather_rows");
     return SVX_OK;
 }

@@ -76,6 +76,14 @@ _SIGS = {
     "svx_unit_rows": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_int]),
     "svx_knn_mean_sim": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_int, c_int, c_vp]),
     "svx_margin_scores": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_int, c_vp]),
+    "svx_mt19937_choice": (c_int, [c_vp, ctypes.POINTER(ctypes.c_int32), c_i64, c_i64, c_vp]),
+    "svx_norm_index_count": (c_i64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "svx_knob_index_count": (c_i64, [c_int, c_int, c_int, c_int]),
+    "svx_draw_indices": (c_int, [c_vp, ctypes.POINTER(ctypes.c_int32), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                 c_vp, c_vp]),
+    "svx_candidate_table": (c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, c_int, c_vp, c_int,
+                                    ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(c_i64), ctypes.c_char_p, c_int]),
+    "svx_format_alignments": (c_i64, [c_vp, c_vp, c_i64, c_vp, c_i64]),
     "svx_num_levels": (c_int, [c_int, c_int, c_int]),
     "svx_knob_count": (c_i64, [c_int, c_int, c_int]),
     "svx_align_batch": (c_int, [c_vp, ctypes.POINTER(AlignParams), ctypes.POINTER(Pair), c_int]),

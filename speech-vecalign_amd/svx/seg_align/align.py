@@ -24,7 +24,7 @@ import numpy as np
 from ..utils.file_utils import check_exist, read_metadata
 from ..utils.log_utils import my_tqdm
 from ..utils.mp_utils import balanced_shards
-from ..vecalign.vecalign import load_document, print_alignments, resolve_search_params
+from ..vecalign.vecalign import resolve_search_params
 
 logger = logging.getLogger(__name__)
 
@@ -52,6 +52,7 @@ def parse_args(argv=None):
                    help="if provided, then some segments will be ignored when loading embeddings.")
     # additive
     p.add_argument("--batch_size", type=int, default=32, help="document pairs per device pass")
+    p.add_argument("--io_threads", type=int, default=None, help="host threads that parse / read ahead of the GPU (default: the CPU count, at most 16)")
     p.add_argument("--seed", type=int, default=None, help="derive one sampling stream per pair from (seed, pair index)")
     p.add_argument("--skip_existing", action="store_true", default=False, help="do not recompute existing outputs")
     p.add_argument("--rank", type=int, default=int(os.environ.get("RANK", 0)))
@@ -110,27 +111,133 @@ def pair_rng(seed: Optional[int], index: int):
     return np.random.RandomState(np.random.SeedSequence([seed, index]).generate_state(4))
 
 
-def align_pairs(pairs: List[VecalignData], args, batch_size: int):
-    from ..vecalign.dp_utils import align_batch
+def format_alignment_rows(rows: np.ndarray, scores: Optional[np.ndarray]) -> bytes:
+    """print_alignments' text (vecalign.py:174-184) for alignment rows (x_start, x_len, y_start, y_len), by the
+    native formatter (svx_format_alignments): byte-identical to the Python '%s:%s:%.6f' of lists."""
+    import ctypes
+    from .. import _lib
+    lib = _lib.load()
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    n = int(rows.shape[0])
+    sc = None if scores is None else np.ascontiguousarray(scores, dtype=np.float64)
+    cap = 64 * n + 16 * int(rows[:, 1].sum() + rows[:, 3].sum()) + 16
+    buf = ctypes.create_string_buffer(cap)
+    need = lib.svx_format_alignments(ctypes.c_void_p(rows.ctypes.data), ctypes.c_void_p(sc.ctypes.data if sc is not None else 0), n, buf, cap)
+    if need < 0 or need > cap:
+        raise Exception("svx_format_alignments: buffer of %d bytes, %d needed" % (cap, need))
+    return buf.raw[:need]
+
+
+def _write_result(path: str, rows: np.ndarray, scores: np.ndarray):
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as fp:  # write-then-rename, the repo's crash-safety idiom
+        fp.write(format_alignment_rows(rows, scores))
+    Path(tmp).replace(path)
+
+
+def _prepare_pair(p: VecalignData, args, src_k: int, tgt_k: int):
+    """Host half of one document pair (runs on a pool thread; the heavy parts are native / I/O and release the
+    GIL): candidate index tables from the segment and candidate files, embedding files into pinned memory."""
+    from ..utils.embedding_utils import candidate_table_from_files, read_embeddings_pinned
+    st, _ = candidate_table_from_files(p.src_seg_path, p.src_concat_path, src_k, p.src_ignore_indices)
+    tt, _ = candidate_table_from_files(p.tgt_seg_path, p.tgt_concat_path, tgt_k, p.tgt_ignore_indices)
+    se = read_embeddings_pinned(p.src_embed_path, args.is_stopes_embed, args.fp16_embed)
+    te = read_embeddings_pinned(p.tgt_embed_path, args.is_stopes_embed, args.fp16_embed)
+    return st, tt, se, te
+
+
+def align_pairs(pairs: List[VecalignData], args, batch_size: int, io_threads: Optional[int] = None, stats: Optional[dict] = None):
+    """The reference's serial loop (align.py:206-230) as a three-stage pipeline around svx_align_batch:
+      host threads   parse segment / candidate files into index tables, read .embed files into pinned memory
+                     (`io_threads`, running ahead by two batches);
+      copy stream    uploads batch i+1 while the compute stream aligns batch i (device gather of the candidate
+                     tensor, then the whole of vecalign());
+      writer threads format and write the alignment files of batch i-1.
+    Results do not depend on the batch size, the thread count or the shard count when --seed is given."""
+    import torch
+    from collections import deque
+    from multiprocessing.pool import ThreadPool
+    from .. import _lib
+    from ..utils.embedding_utils import gather_candidates
+    from ..vecalign.dp_utils import PreparedBatch
     types, src_k, tgt_k, width_over2 = resolve_search_params(args.alignment_max_size, None, args.search_buffer_size)
     todo = [p for p in pairs if not (args.skip_existing and Path(p.output_path).exists())]
-    for b0 in my_tqdm(range(0, len(todo), batch_size)):
-        chunk = todo[b0:b0 + batch_size]
+    if not todo:
+        return
+    ctx = _lib.context()
+    dev = ctx.tdev
+    nthr = io_threads or max(2, min(16, (os.cpu_count() or 4)))
+    io_pool, out_pool = ThreadPool(nthr), ThreadPool(max(2, nthr // 2))
+    copy_stream = torch.cuda.Stream(device=dev)
+    compute = torch.cuda.current_stream(dev)
+    batches = [todo[b0:b0 + batch_size] for b0 in range(0, len(todo), batch_size)]
+    ahead = deque()   # (chunk, [async results of _prepare_pair])
+    nxt = 0
+
+    def submit_more():
+        nonlocal nxt
+        while nxt < len(batches) and len(ahead) < 3:
+            ahead.append((batches[nxt], [io_pool.apply_async(_prepare_pair, (p, args, src_k, tgt_k)) for p in batches[nxt]]))
+            nxt += 1
+
+    def finish(job):
+        chunk, pb, ev, held = job
+        ev.synchronize()
+        info, align, scores, _, offs = pb.raw_results()
+        writes = []
+        for i, p in enumerate(chunk):
+            o, cnt = int(offs[i]), int(info[i, 0])
+            writes.append(out_pool.apply_async(_write_result, (p.output_path, align[o:o + cnt], scores[o:o + cnt])))
+        return writes, (pb, held)  # (the pinned result buffers stay alive until the writers are done)
+
+    pending_job, pending_writes = None, deque()
+    submit_more()
+    bar = my_tqdm(total=len(todo))
+    while ahead:
+        chunk, futs = ahead.popleft()
+        submit_more()
+        prepared = [f.get() for f in futs]
+        # ---- uploads on the copy stream (pinned -> device), then gather + align on the compute stream
+        with torch.cuda.stream(copy_stream):
+            dev_in = [(torch.from_numpy(st).to(dev, non_blocking=True), torch.from_numpy(tt).to(dev, non_blocking=True),
+                       se.to(dev, non_blocking=True), te.to(dev, non_blocking=True)) for st, tt, se, te in prepared]
+            up = torch.cuda.Event()
+            up.record(copy_stream)
+        compute.wait_event(up)
         docs = []
-        for p in chunk:
-            _, sv = load_document(p.src_seg_path, [p.src_concat_path, p.src_embed_path], args.is_stopes_embed,
-                                  args.fp16_embed, src_k, p.src_ignore_indices, True)
-            _, tv = load_document(p.tgt_seg_path, [p.tgt_concat_path, p.tgt_embed_path], args.is_stopes_embed,
-                                  args.fp16_embed, tgt_k, p.tgt_ignore_indices, True)
+        for (st, tt, se, te), (dst, dtt, dse, dte) in zip(prepared, dev_in):
+            for x in (dst, dtt, dse, dte):
+                x.record_stream(compute)
+            sv, tv = gather_candidates(dse, dst), gather_candidates(dte, dtt)
+            if sv.dtype != tv.dtype:
+                sv, tv = sv.float(), tv.float()
             docs.append((sv, tv))
         rngs = None if args.seed is None else [pair_rng(args.seed, p.index) for p in chunk]
-        results = align_batch(docs, types, args.del_percentile_frac, width_over2, args.max_size_full_dp,
-                              args.costs_sample_size, args.num_samps_for_norm, rngs=rngs)
-        for p, (alignments, scores, _) in zip(chunk, results):
-            tmp = p.output_path + ".tmp"
-            with open(tmp, "w") as fp:  # write-then-rename, the repo's crash-safety idiom
-                print_alignments(alignments, scores=scores, ofile=fp)
-            Path(tmp).replace(p.output_path)
+        pb = PreparedBatch(docs, types, args.del_percentile_frac, width_over2, args.max_size_full_dp,
+                           args.costs_sample_size, args.num_samps_for_norm, rngs=rngs)
+        pb.run()
+        ev = pb.fetch_async()
+        job = (chunk, pb, ev, (prepared, dev_in))
+        # ---- while this batch computes: hand the previous batch to the writers
+        if pending_job is not None:
+            pending_writes.append(finish(pending_job))
+            bar.update(len(pending_job[0]))
+        pending_job = job
+        while len(pending_writes) > 1:
+            for w in pending_writes.popleft()[0]:
+                w.get()
+    if pending_job is not None:
+        pending_writes.append(finish(pending_job))
+        bar.update(len(pending_job[0]))
+    for writes, _ in pending_writes:
+        for w in writes:
+            w.get()
+    bar.close()
+    io_pool.close()
+    out_pool.close()
+    if stats is not None:
+        stats["pairs"] = len(todo)
+        stats["io_threads"] = nthr
 
 
 def main(argv=None):
@@ -155,7 +262,7 @@ def main(argv=None):
         costs = [os.path.getsize(p.src_embed_path) + os.path.getsize(p.tgt_embed_path) for p in valid]
         valid = [valid[i] for i in balanced_shards(costs, args.n_shard)[args.rank]]
         logger.info(f"rank {args.rank} of {args.n_shard}: {len(valid)} pairs")
-    align_pairs(valid, args, max(1, args.batch_size))
+    align_pairs(valid, args, max(1, args.batch_size), io_threads=args.io_threads)
 
 
 if __name__ == '__main__':

@@ -101,6 +101,66 @@ def candidate_index_table(sent2id: dict, lines: List[str], max_overlaps: int,
     return table
 
 
+def candidate_table_from_files(seg_file: str, cat_file: str, max_overlaps: int, ignore_file: Optional[str] = None):
+    """candidate_index_table for speech segments straight from the files (svx_candidate_table, native and
+    GIL-free: a thread pool can build the tables of many documents at once): -> (int32 [max_overlaps, n_lines],
+    number of candidate lines).  String keys exactly as the reference builds them (embedding_utils.py:93-99,128);
+    NaN rows are handled by the device gather."""
+    import ctypes
+    import os
+    from .. import _lib
+    lib = _lib.load()
+    cap = os.path.getsize(seg_file) // 2 + 2  # a line has at least two bytes
+    table = np.empty((max_overlaps, cap), dtype=np.int32)
+    n_lines, n_cand = ctypes.c_int32(0), ctypes.c_int64(0)
+    err = ctypes.create_string_buffer(512)
+    ign = None if ignore_file is None else os.fspath(ignore_file).encode()
+    rc = lib.svx_candidate_table(os.fspath(seg_file).encode(), os.fspath(cat_file).encode(), ign, int(max_overlaps),
+                                 ctypes.c_void_p(table.ctypes.data), int(cap), ctypes.byref(n_lines), ctypes.byref(n_cand), err, 512)
+    if rc != 0:
+        raise Exception(err.value.decode(errors="replace") or "svx_candidate_table failed")
+    return np.ascontiguousarray(table[:, :n_lines.value]), int(n_cand.value)
+
+
+def embedding_file_layout(embed_file: str, use_stopes: bool = False, fp16_embed: bool = False):
+    """-> (byte offset of the first row, number of rows, numpy dtype) of an .embed file: stopes files are NumPy
+    .npy v1/v2 ('<f2' or '<f4', C order, [n, 1024]); the others are headerless fp16 / fp32 (embedding_utils.py:38-76)."""
+    import os
+    size = os.path.getsize(embed_file)
+    if use_stopes:
+        with open(embed_file, "rb") as f:
+            major, _ = np.lib.format.read_magic(f)
+            shape, fortran, dt = (np.lib.format.read_array_header_1_0(f) if major == 1 else np.lib.format.read_array_header_2_0(f))
+            off = f.tell()
+        if fortran or len(shape) != 2 or dt not in (np.dtype('<f2'), np.dtype('<f4')):
+            raise Exception('stopes embedding file %s: unsupported layout %s %s' % (embed_file, shape, dt))
+        return off, int(shape[0]), dt, int(shape[1])
+    dt = np.dtype(np.float16 if fp16_embed else np.float32)
+    if size == 0:
+        raise Exception('Got empty embedding file')
+    return 0, size // (EMBED_DIM * dt.itemsize), dt, EMBED_DIM
+
+
+def read_embeddings_pinned(embed_file: str, use_stopes: bool = False, fp16_embed: bool = False):
+    """The embedding matrix of a file read into page-locked host memory (one readinto, GIL released), as a
+    torch tensor [n_rows, d] in the file's storage type, ready for an asynchronous upload."""
+    import torch
+    off, rows, dt, d = embedding_file_layout(embed_file, use_stopes, fp16_embed)
+    tdt = torch.float16 if dt.itemsize == 2 else torch.float32
+    host = torch.empty((rows, d), dtype=tdt, pin_memory=torch.cuda.is_available())
+    view = host.numpy().reshape(-1).view(np.uint8)
+    with open(embed_file, "rb", buffering=0) as f:
+        f.seek(off)
+        got = 0
+        mv = memoryview(view)
+        while got < view.size:
+            n = f.readinto(mv[got:])
+            if not n:
+                raise Exception('%s is shorter than its header says' % embed_file)
+            got += n
+    return host
+
+
 def gather_candidates(line_embeddings, table: np.ndarray, device=None):
     """Device gather (svx_gather_rows): out[j, i] = line_embeddings[table[j, i]] or 0 -> torch tensor [K, N, d]."""
     import ctypes
@@ -109,7 +169,7 @@ def gather_candidates(line_embeddings, table: np.ndarray, device=None):
     t = ctx.torch
     # (np.array copies: the file readers hand out read-only memory maps)
     emb = line_embeddings if hasattr(line_embeddings, "data_ptr") else t.from_numpy(np.array(line_embeddings))
-    emb = emb.to(ctx.tdev).contiguous()
+    emb = emb.to(ctx.tdev, non_blocking=True).contiguous()
     dt = {t.float32: _lib.SVX_F32, t.float16: _lib.SVX_F16, t.bfloat16: _lib.SVX_BF16}[emb.dtype]
     idx = t.from_numpy(np.ascontiguousarray(table, dtype=np.int32)).to(ctx.tdev)
     out = t.empty(tuple(table.shape) + (emb.shape[1],), dtype=emb.dtype, device=ctx.tdev)
@@ -121,8 +181,7 @@ def gather_candidates(line_embeddings, table: np.ndarray, device=None):
 def make_doc_embedding(sent2id: dict, line_embeddings: np.ndarray, lines: List[str], max_overlaps: int,
                        ignore_indices: Optional[Set[Tuple[int, int]]] = None, overlap_segments: bool = False,
                        device=None):
-    """-> device tensor [max_overlaps, len(lines), d] (embedding_utils.py:135-203)."""
-    arr = np.asarray(line_embeddings)
-    bad = np.isnan(arr).any(axis=1) if arr.size else None
-    table = candidate_index_table(sent2id, lines, max_overlaps, ignore_indices, overlap_segments, bad)
+    """-> device tensor [max_overlaps, len(lines), d] (embedding_utils.py:135-203).  Rows of the embedding file that
+    hold a NaN come out as zero rows like in the reference (:183-190); the device gather tests for them."""
+    table = candidate_index_table(sent2id, lines, max_overlaps, ignore_indices, overlap_segments)
     return gather_candidates(line_embeddings, table, device)

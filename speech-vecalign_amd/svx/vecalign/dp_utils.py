@@ -28,6 +28,19 @@ logger = logging.getLogger('vecalign')  # same logger name as the reference (dp_
 
 
 # ------------------------------------------------------------------------------------- helpers
+_pool = None
+
+
+def _draw_pool():
+    """Threads for the GIL-free native host helpers (index drawing, file parsing)."""
+    global _pool
+    if _pool is None:
+        import os
+        from multiprocessing.pool import ThreadPool
+        _pool = ThreadPool(max(2, min(16, (os.cpu_count() or 4))))
+    return _pool
+
+
 def _ctx():
     return _lib.context()
 
@@ -105,6 +118,39 @@ def draw_indices(n, m, k0, k1, max_size_full_dp, costs_sample_size, num_samps_fo
     return norm_idx, knob_idx
 
 
+def index_counts(n, m, k0, k1, max_size_full_dp, costs_sample_size, num_samps_for_norm, have_norms0=False, have_norms1=False):
+    """(len(norm_idx), len(knob_idx)) of draw_indices for a pair of these sizes."""
+    lib = _lib.load()
+    return (int(lib.svx_norm_index_count(n, m, k0, k1, max_size_full_dp, num_samps_for_norm, int(have_norms0), int(have_norms1))),
+            int(lib.svx_knob_index_count(n, m, max_size_full_dp, costs_sample_size)))
+
+
+def draw_indices_into(norm_out, knob_out, n, m, k0, k1, max_size_full_dp, costs_sample_size, num_samps_for_norm, rng=None,
+                      have_norms0=False, have_norms1=False):
+    """draw_indices() written straight into int32 buffers (numpy views, e.g. of pinned staging memory), by the
+    native MT19937 restatement of RandomState.choice (svx_draw_indices): the same stream, bit for bit, at a
+    fraction of the cost, and without the GIL, so a thread pool can draw for many pairs at once.  `rng` is a
+    numpy RandomState (advanced like the numpy calls would) or None for numpy's global legacy stream."""
+    lib = _lib.load()
+    st = np.random.get_state() if rng is None else rng.get_state()
+    if st[0] != 'MT19937':
+        raise ValueError("draw_indices_into needs a legacy MT19937 RandomState")
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = ctypes.c_int32(int(st[2]))
+    assert norm_out.dtype == np.int32 and knob_out.dtype == np.int32 and norm_out.flags.c_contiguous and knob_out.flags.c_contiguous
+    rc = lib.svx_draw_indices(ctypes.c_void_p(key.ctypes.data), ctypes.byref(pos), int(n), int(m), int(k0), int(k1),
+                              int(max_size_full_dp), int(costs_sample_size), int(num_samps_for_norm), int(have_norms0),
+                              int(have_norms1), ctypes.c_void_p(norm_out.ctypes.data if norm_out.size else 0),
+                              ctypes.c_void_p(knob_out.ctypes.data))
+    if rc != 0:
+        raise ValueError("svx_draw_indices: bad argument")
+    new = ('MT19937', key, int(pos.value), st[3], st[4])
+    if rng is None:
+        np.random.set_state(new)
+    else:
+        rng.set_state(new)
+
+
 # ------------------------------------------------------------------------------------- batch
 class PreparedBatch:
     """A batch of document pairs resident on the device, ready for `run()` (svx_align_batch).
@@ -159,21 +205,36 @@ class PreparedBatch:
         self.scores = t.zeros(int(offs[-1]), dtype=t.float64, device=ctx.tdev)
         self.info = t.zeros((npairs, 2), dtype=t.int32, device=ctx.tdev)
         self.del_pen = t.zeros((npairs, _lib.SVX_MAX_LEVELS), dtype=t.float64, device=ctx.tdev)
-        norm_chunks, knob_chunks, norm_offs, knob_offs = [], [], [0], [0]
+        # sampled indices: sizes are a function of the shapes, so one pinned staging buffer per kind is laid out
+        # first and filled in place (native generator; per-pair streams are independent, so they fill in parallel)
+        norm_offs, knob_offs = [0], [0]
         for i, (a, b) in enumerate(self.vecs):
             k0, n = int(a.shape[0]), int(a.shape[1])
             k1, m = int(b.shape[0]), int(b.shape[1])
             nrm = norms[i] if norms is not None else (None, None)
-            rng = rngs[i] if rngs is not None else None
-            ni, ki = draw_indices(n, m, k0, k1, max_size_full_dp, costs_sample_size, num_samps_for_norm, rng,
+            nn, kn = index_counts(n, m, k0, k1, max_size_full_dp, costs_sample_size, num_samps_for_norm,
                                   nrm[0] is not None, nrm[1] is not None)
-            norm_chunks.append(ni)
-            knob_chunks.append(ki)
-            norm_offs.append(norm_offs[-1] + len(ni))
-            knob_offs.append(knob_offs[-1] + len(ki))
+            norm_offs.append(norm_offs[-1] + nn)
+            knob_offs.append(knob_offs[-1] + kn)
             self.levels.append(len(level_sizes(n, m, max_size_full_dp)))
-        self.norm_idx = t.from_numpy(np.concatenate(norm_chunks)).to(ctx.tdev)
-        self.knob_idx = t.from_numpy(np.concatenate(knob_chunks)).to(ctx.tdev)
+        h_norm = t.empty(max(1, norm_offs[-1]), dtype=t.int32, pin_memory=True)
+        h_knob = t.empty(max(1, knob_offs[-1]), dtype=t.int32, pin_memory=True)
+        hn, hk = h_norm.numpy(), h_knob.numpy()
+
+        def draw(i):
+            a, b = self.vecs[i]
+            nrm = norms[i] if norms is not None else (None, None)
+            draw_indices_into(hn[norm_offs[i]:norm_offs[i + 1]], hk[knob_offs[i]:knob_offs[i + 1]], int(a.shape[1]), int(b.shape[1]),
+                              int(a.shape[0]), int(b.shape[0]), max_size_full_dp, costs_sample_size, num_samps_for_norm,
+                              rngs[i] if rngs is not None else None, nrm[0] is not None, nrm[1] is not None)
+        if rngs is not None and npairs >= 8:
+            _draw_pool().map(draw, range(npairs))
+        else:  # the global stream is consumed pair after pair, like the reference's serial loop
+            for i in range(npairs):
+                draw(i)
+        self.norm_idx = h_norm.to(ctx.tdev, non_blocking=True)
+        self.knob_idx = h_knob.to(ctx.tdev, non_blocking=True)
+        self.keep.append((h_norm, h_knob))
         for i, (a, b) in enumerate(self.vecs):
             c = self.cpairs[i]
             c.vecs0, c.vecs1 = a.data_ptr(), b.data_ptr()
@@ -201,20 +262,38 @@ class PreparedBatch:
         ctx.use_current_stream()
         ctx.check(ctx.lib.svx_align_batch(ctx.h, ctypes.byref(self.prm), self.cpairs, len(self.vecs)))
 
+    def fetch_async(self):
+        """Queue the device -> pinned-host copies of the outputs behind run() on the current stream and return
+        an event that fires when they have landed (the host pipeline formats batch i while batch i+1 computes)."""
+        t = self.ctx.torch
+        self.h_out = tuple(t.empty(x.shape, dtype=x.dtype, pin_memory=True) for x in (self.info, self.align, self.scores, self.del_pen))
+        for h, d in zip(self.h_out, (self.info, self.align, self.scores, self.del_pen)):
+            h.copy_(d, non_blocking=True)
+        ev = t.cuda.Event()
+        ev.record(t.cuda.current_stream(self.ctx.tdev))
+        return ev
+
+    def raw_results(self):
+        """-> (info [P][2], rows [sum][4], scores [sum], del_pen [P][levels], offsets) as numpy arrays, after
+        checking every pair's status.  Uses the copies of fetch_async() when there are any."""
+        if getattr(self, "h_out", None) is not None:
+            info, align, scores, pens = (h.numpy() for h in self.h_out)
+        else:
+            self.ctx.sync()
+            info, align, scores, pens = (x.cpu().numpy() for x in (self.info, self.align, self.scores, self.del_pen))
+        bad = np.nonzero((info[:, 1] != 0) | (info[:, 0] < 0))[0]
+        if len(bad):
+            cnt, err = int(info[bad[0], 0]), int(info[bad[0], 1])
+            code = err if err != 0 else -cnt
+            raise Exception(_lib.DEVICE_ERRORS.get(code, "device failure %d" % code))
+        return info, align, scores, pens, self.offs
+
     def results(self):
         """-> list of (alignments, scores, del_penalties) per pair; raises on a device-side failure."""
-        self.ctx.sync()
-        info = self.info.cpu().numpy()
-        align = self.align.cpu().numpy()
-        scores = self.scores.cpu().numpy()
-        pens = self.del_pen.cpu().numpy()
+        info, align, scores, pens, offs = self.raw_results()
         out = []
         for i in range(len(self.vecs)):
-            cnt, err = int(info[i, 0]), int(info[i, 1])
-            if err != 0 or cnt < 0:
-                code = err if err != 0 else -cnt
-                raise Exception(_lib.DEVICE_ERRORS.get(code, "device failure %d" % code))
-            o = int(self.offs[i])
+            cnt, o = int(info[i, 0]), int(offs[i])
             out.append((rows_to_alignments(align[o:o + cnt]), scores[o:o + cnt].copy(), pens[i, :self.levels[i]].copy()))
         return out
 

@@ -105,8 +105,13 @@ def resolve_search_params(alignment_max_size: int, many_to_one: Optional[int], s
 def load_document(seg_file, embed: List[str], use_stopes: bool, fp16: bool, max_overlaps: int,
                   ignore_indices: Optional[Union[str, Path]], overlap_segments: bool):
     """-> (lines, candidate tensor [max_overlaps, n_lines, d] on the device)."""
-    sent2id, embeddings = read_in_embeddings(embed[0], embed[1], use_stopes, fp16)
     lines = open(seg_file, 'rt', encoding="utf-8").readlines()
+    if overlap_segments:
+        # speech segments: the table comes from the native parser, the rows go file -> pinned memory -> device
+        from ..utils.embedding_utils import candidate_table_from_files, gather_candidates, read_embeddings_pinned
+        table, _ = candidate_table_from_files(seg_file, embed[0], max_overlaps, ignore_indices)
+        return lines, gather_candidates(read_embeddings_pinned(embed[1], use_stopes, fp16), table)
+    sent2id, embeddings = read_in_embeddings(embed[0], embed[1], use_stopes, fp16)
     vectors = make_doc_embedding(sent2id, embeddings, lines, max_overlaps,
                                  ignore_indices=load_ignore_index_file(ignore_indices) if ignore_indices else None,
                                  overlap_segments=overlap_segments)

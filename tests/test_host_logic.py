@@ -320,3 +320,67 @@ def test_sort_tsv_reproduces_shipped_manifest(tmp_path):
     assert scores == sorted(scores, reverse=True)
     with pytest.raises(AssertionError, match="exists"):
         sort_tsv.main(["--in_tsv", os.path.join(POST, "align.rm_overlap.tsv.gz"), "--out_tsv", str(out)])
+
+
+def test_native_index_drawing_matches_numpy_stream():
+    """svx_draw_indices / svx_mt19937_choice restate RandomState.choice (MT19937 + masked rejection) bit for bit and
+    leave the stream where numpy would: per-pair generators and the global legacy stream."""
+    from svx.vecalign import dp_utils as D
+    cases = [(4096, 4096, 4, 4, 300, 20000, 100, False, False), (237, 217, 5, 5, 300, 20000, 100, False, False),
+             (40, 37, 3, 3, 300, 20000, 100, False, False), (1101, 1003, 4, 3, 50, 5000, 30, True, False),
+             (700, 1, 2, 2, 300, 20000, 100, False, True), (1, 1, 1, 1, 300, 20000, 100, False, False),
+             (333, 1200, 4, 4, 300, 20000, 7, True, True), (65536, 3, 2, 1, 10, 999, 1, False, False)]
+    for (n, m, k0, k1, mf, cs, ns, h0, h1) in cases:
+        r1, r2 = np.random.RandomState(7), np.random.RandomState(7)
+        a, b = D.draw_indices(n, m, k0, k1, mf, cs, ns, r1, h0, h1)
+        nn, kn = D.index_counts(n, m, k0, k1, mf, cs, ns, h0, h1)
+        no, ko = np.zeros(nn, np.int32), np.zeros(kn, np.int32)
+        D.draw_indices_into(no, ko, n, m, k0, k1, mf, cs, ns, r2, h0, h1)
+        assert np.array_equal(a[:nn], no) and np.array_equal(b, ko), (n, m)
+        assert r1.randint(0, 10 ** 9) == r2.randint(0, 10 ** 9)   # both streams stand at the same place
+    np.random.seed(3)
+    a, b = D.draw_indices(900, 800, 4, 4, 300, 20000, 100)
+    after = np.random.randint(0, 10 ** 9)
+    np.random.seed(3)
+    no, ko = np.zeros(len(a), np.int32), np.zeros(len(b), np.int32)
+    D.draw_indices_into(no, ko, 900, 800, 4, 4, 300, 20000, 100)
+    assert np.array_equal(a, no) and np.array_equal(b, ko) and np.random.randint(0, 10 ** 9) == after
+
+
+@pytest.mark.parametrize("fixture", ["example_trim", "example_full"])
+def test_native_candidate_table_and_formatter(fixture, tmp_path):
+    """svx_candidate_table == the Python mirror of make_overlap + dict lookup (string keys, ignore entries, PAD
+    triangle) on the shipped example; svx_format_alignments == print_alignments byte for byte."""
+    import io
+    from svx.seg_align.align import format_alignment_rows
+    from svx.utils import embedding_utils as E
+    from svx.utils.file_utils import read_alignments_with_score
+    from svx.vecalign.dp_utils import alignments_to_rows
+    from svx.vecalign.vecalign import load_ignore_index_file, print_alignments
+    D = os.path.join(ROOT, "tests", "golden", fixture)
+    for lang, side in (("en", "src"), ("de", "tgt")):
+        s2i, emb = E.read_in_embeddings(f"{D}/cat_segs_{lang}.txt", f"{D}/embeds_{lang}.f16", False, True)
+        lines = open(f"{D}/segments_{lang}.txt").readlines()
+        ign = load_ignore_index_file(f"{D}/ignore_{side}.txt")
+        for K, ig, igf in ((5, ign, f"{D}/ignore_{side}.txt"), (3, None, None), (7, ign, f"{D}/ignore_{side}.txt")):
+            want = E.candidate_index_table(s2i, lines, K, ig, overlap_segments=True)
+            got, ncand = E.candidate_table_from_files(f"{D}/segments_{lang}.txt", f"{D}/cat_segs_{lang}.txt", K, igf)
+            assert np.array_equal(want, got) and ncand == emb.shape[0]
+        host = E.read_embeddings_pinned(f"{D}/embeds_{lang}.f16", False, True)
+        assert np.array_equal(host.numpy(), np.asarray(emb))
+    # duplicate candidate lines keep the first row; CRLF and blank lines; a missing candidate is -1
+    (tmp_path / "seg.txt").write_text("0 10\r\n10 25\n\n")
+    (tmp_path / "cat.txt").write_text("10 25\n0 10\n0 25\n0 10\n")
+    with pytest.raises(Exception, match="start and an end"):
+        E.candidate_table_from_files(str(tmp_path / "seg.txt"), str(tmp_path / "cat.txt"), 2)
+    (tmp_path / "seg.txt").write_text("0 10\r\n10 25\n25 31\n")
+    got, ncand = E.candidate_table_from_files(str(tmp_path / "seg.txt"), str(tmp_path / "cat.txt"), 2)
+    assert ncand == 4 and got.tolist() == [[1, 0, -1], [-1, 2, -1]]
+    exp = read_alignments_with_score(os.path.join(D, "expected_seed0.txt"))
+    al, sc = [(a, b) for a, b, _ in exp], np.array([s for _, _, s in exp]) + 1e-7
+    buf = io.StringIO()
+    print_alignments(al, scores=sc, ofile=buf)
+    assert format_alignment_rows(alignments_to_rows(al), sc) == buf.getvalue().encode()
+    buf = io.StringIO()
+    print_alignments(al, ofile=buf)
+    assert format_alignment_rows(alignments_to_rows(al), None) == buf.getvalue().encode()
