@@ -504,7 +504,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
                 if (cap > max_A[l]) max_A[l] = cap;
                 OFF(Lv.path, (size_t)cap * 2 * sizeof(int));
                 OFF(Lv.path_len, sizeof(int));
-                OFF(Lv.cstart, (size_t)(cap / SVX_BC_TA + 3) * sizeof(int));
+                OFF(Lv.cstart, (size_t)(cap / 16 + 3) * sizeof(int));  // a chunk holds at least 17 path points
                 OFF(Lv.nchunks, sizeof(int));
                 OFF(Lv.costs, (size_t)(T > 0 ? T : 1) * cap * B * sizeof(float));
                 OFF(Lv.boff, (size_t)cap * sizeof(int));
@@ -635,15 +635,20 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         const int first_depth = maxL > 0 ? maxL - 1 : 0;
         for (int depth = first_depth; depth >= 0; depth--) {
             const SvxTypes& ty = depth == 0 ? tfinal : t11;
+            int lim2 = 0, tamax2 = 0;
+            const bool v2 = svxl_band2_limits(ty, W, depth, &lim2, &tamax2);  // which band-cost kernel takes this level
             {
                 StageScope sc(ctx, S_PATH);
                 // (pairs whose source level has more alignment rows than the LDS holds take the kernel's serial path)
                 const int src_rows = (maxL > 0 && !any_L0) ? max_A[depth] / 2 + 8 : max_A[depth];
-                if ((rc2 = svxl_search_path_batch(ctx, dp, np, depth, max_A[depth], src_rows))) return rc2;
+                if ((rc2 = svxl_search_path_batch(ctx, dp, np, depth, max_A[depth], src_rows, v2 ? lim2 : SVX_BC_ROWS - SVX_BC_TB,
+                                                  v2 ? tamax2 : SVX_BC_TAMAX))) return rc2;
             }
             {
                 StageScope sc(ctx, depth == 0 ? S_BAND_COSTS0 : S_BAND_COSTSN);
-                if ((rc2 = svxl_band_costs_batch(ctx, dp, np, depth, max_A[depth], ty, W, dtype, d))) return rc2;
+                if (v2) rc2 = svxl_band_costs2_batch(ctx, dp, np, depth, max_A[depth], ty, W, dtype, d);
+                else rc2 = svxl_band_costs_batch(ctx, dp, np, depth, max_A[depth], ty, W, dtype, d);
+                if (rc2) return rc2;
             }
             {
                 StageScope sc(ctx, depth == 0 ? S_BAND_DP0 : S_BAND_DPN);

@@ -206,6 +206,10 @@ int svxl_band_costs(svx_ctx*, const void* v0, int k0, int n, const void* v1, int
                     int A, const SvxTypes& types, int W, float* costs, int* boff, int* status);
 int svxl_band_costs_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int max_A, const SvxTypes& types,
                           int W, int dtype, int d);
+// costs, second-generation band kernel of the fused pipeline (svx_band.hip)
+bool svxl_band2_limits(const SvxTypes& types, int W, int depth, int* lim, int* tamax);
+int svxl_band_costs2_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int max_A, const SvxTypes& types, int W,
+                           int dtype, int d);
 // dp (svx_dp.hip)
 int svxl_dense_dp(svx_ctx*, const float* cost, int s0, int s1, float pen, double* csum, int* bp);
 int svxl_dense_stage_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_s0);
@@ -218,6 +222,7 @@ int svxl_sparse_traceback(svx_ctx*, const double* csum, const int* xp, const int
 int svxl_sparse_traceback_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int B, int max_A, int packed);
 int svxl_search_path(svx_ctx*, const int* align, const int* n_align, int upsample, int size0, int size1, int* path,
                      int cap, int* path_len);
-int svxl_search_path_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int max_rows, int max_src_rows);
+int svxl_search_path_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int max_rows, int max_src_rows, int chunk_lim,
+                           int chunk_tamax);
 int svxl_del_penalty(svx_ctx*, const float* scores, int64_t n, double frac, double* out);
 int svxl_del_penalty_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_levels, double frac);

@@ -1002,14 +1002,13 @@ __global__ __launch_bounds__(256) void k_search_path_batch(const SvxPairDev* __r
 // target extents both stay within SVX_BC_ROWS - SVX_BC_TB rows, so that a chunk's cells never leave the rows its
 // workgroup stages.  The end of the chunk that starts at s is found for every s at once (the path is monotone:
 // binary search), then thread 0 hops from chunk start to chunk start.
-__global__ __launch_bounds__(256) void k_chunk_path(const SvxPairDev* __restrict__ pairs, int depth, int lds_ints) {
+__global__ __launch_bounds__(256) void k_chunk_path(const SvxPairDev* __restrict__ pairs, int depth, int lds_ints, int LIM, int TAMAX) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* nxt = reinterpret_cast<int*>(smem);
     const SvxPairDev& P = pairs[blockIdx.x];
     if (depth > P.L || (depth == P.L && P.L > 0)) return;
     const SvxLevel& Lv = P.lev[depth];
     const int A = *Lv.path_len;
-    constexpr int LIM = SVX_BC_ROWS - SVX_BC_TB;
     if (A <= 0 || *P.status != 0) {
         if (threadIdx.x == 0) *Lv.nchunks = 0;
         return;
@@ -1018,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_chunk_path(const SvxPairDev* __restrict
     if (A <= lds_ints) {
         for (int s0 = threadIdx.x; s0 < A; s0 += 256) {
             const int2 p0 = path[s0];
-            int lo = s0 + 1, hi = (s0 + SVX_BC_TAMAX) < A ? (s0 + SVX_BC_TAMAX) : A;
+            int lo = s0 + 1, hi = (s0 + TAMAX) < A ? (s0 + TAMAX) : A;
             while (lo < hi) {  // smallest i in (s0, hi] that is hi or leaves the window
                 const int mid = (lo + hi) >> 1;
                 const int2 p = path[mid];
@@ -1040,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_chunk_path(const SvxPairDev* __restrict
         Lv.cstart[0] = 0;
         for (int i = 1; i < A; i++) {
             const int2 p = path[i];
-            if (i - s0 >= SVX_BC_TAMAX || p.x - p0.x > LIM || p.y - p0.y > LIM) {
+            if (i - s0 >= TAMAX || p.x - p0.x > LIM || p.y - p0.y > LIM) {
                 Lv.cstart[++nc] = i;
                 s0 = i;
                 p0 = p;
@@ -1348,7 +1347,8 @@ int svxl_search_path(svx_ctx* ctx, const int* align, const int* n_align, int ups
 
 // max_rows: path capacity of the longest pair at this depth; max_src_rows: alignment rows of the level the path is
 // built from (half as many when it is the up-sampled coarser level) -- what the path kernel keeps in LDS.
-int svxl_search_path_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int depth, int max_rows, int max_src_rows) {
+int svxl_search_path_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int depth, int max_rows, int max_src_rows, int chunk_lim,
+                           int chunk_tamax) {
     if (n_pairs <= 0) return SVX_OK;
     size_t smem;
     const int rows = sp_lds_rows(max_src_rows, &smem);
@@ -1361,7 +1361,7 @@ int svxl_search_path_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, i
     const size_t csmem = (size_t)ints * sizeof(int);
     if (csmem > 64 * 1024)
         SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_chunk_path, hipFuncAttributeMaxDynamicSharedMemorySize, (int)csmem));
-    hipLaunchKernelGGL(k_chunk_path, dim3(n_pairs), dim3(256), csmem, ctx->stream, pairs, depth, ints);
+    hipLaunchKernelGGL(k_chunk_path, dim3(n_pairs), dim3(256), csmem, ctx->stream, pairs, depth, ints, chunk_lim, chunk_tamax);
     SVX_LAUNCH_CHECK(ctx, "k_chunk_path");
     return SVX_OK;
 }

@@ -171,7 +171,10 @@ def gather_candidates(line_embeddings, table: np.ndarray, device=None):
     emb = line_embeddings if hasattr(line_embeddings, "data_ptr") else t.from_numpy(np.array(line_embeddings))
     emb = emb.to(ctx.tdev, non_blocking=True).contiguous()
     dt = {t.float32: _lib.SVX_F32, t.float16: _lib.SVX_F16, t.bfloat16: _lib.SVX_BF16}[emb.dtype]
-    idx = t.from_numpy(np.ascontiguousarray(table, dtype=np.int32)).to(ctx.tdev)
+    if hasattr(table, "data_ptr"):
+        idx = table.to(ctx.tdev, dtype=t.int32).contiguous()
+    else:
+        idx = t.from_numpy(np.ascontiguousarray(table, dtype=np.int32)).to(ctx.tdev)
     out = t.empty(tuple(table.shape) + (emb.shape[1],), dtype=emb.dtype, device=ctx.tdev)
     ctx.check(ctx.lib.svx_gather_rows(ctx.h, ctypes.c_void_p(emb.data_ptr()), int(emb.shape[0]), int(emb.shape[1]), dt,
                                       ctypes.c_void_p(idx.data_ptr()), int(idx.numel()), ctypes.c_void_p(out.data_ptr())))
