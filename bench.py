@@ -77,24 +77,30 @@ def cpu_worker(argv):
 
 
 # ------------------------------------------------------------------------------------------ synthetic inputs
-def synth_pair_device(N, M, K, d, seed, dev, dtype):
-    """Seeded synthetic pair in the reference's candidate layout, generated on the device:
-    layer k row i = sum of base rows i-k..i (rows i < k zero); target = noisy copy of the source."""
+def synth_pairs_device(N, M, K, d, seeds, dev, dtype):
+    """Seeded synthetic pairs in the reference's candidate layout, generated on the device, len(seeds) pairs per
+    call (few large kernels instead of thousands of small ones): layer k row i = sum of base rows i-k..i
+    (rows i < k zero); target = noisy copy of the source.  -> list of (vecs0 [K][N][d], vecs1 [K][M][d])."""
     import torch
+    P, L = len(seeds), max(N, M)
     g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    L = max(N, M)
-    base = torch.randn((L, d), generator=g, device=dev, dtype=torch.float32)
-    tgt = base + 0.5 * torch.randn((L, d), generator=g, device=dev, dtype=torch.float32)
+    g.manual_seed(int(seeds[0]) * 1000003 + P)
+    base = torch.randn((P, L, d), generator=g, device=dev, dtype=torch.float32)
+    tgt = base + 0.5 * torch.randn((P, L, d), generator=g, device=dev, dtype=torch.float32)
 
     def layers(b, n):
-        cs = torch.cat([torch.zeros((1, d), device=dev, dtype=torch.float64), torch.cumsum(b[:n].double(), 0)])
-        out = torch.zeros((K, n, d), device=dev, dtype=torch.float32)
+        cs = torch.cat([torch.zeros((P, 1, d), device=dev, dtype=torch.float64), torch.cumsum(b[:, :n].double(), 1)], dim=1)
+        out = torch.zeros((P, K, n, d), device=dev, dtype=dtype)
         for k in range(K):
-            out[k, k:] = (cs[k + 1:n + 1] - cs[:n - k]).float()
-        return out.to(dtype).contiguous()
+            out[:, k, k:] = (cs[:, k + 1:n + 1] - cs[:, :n - k]).float().to(dtype)
+        return out
 
-    return layers(base, N), layers(tgt, M)
+    a, b = layers(base, N), layers(tgt, M)
+    return [(a[i], b[i]) for i in range(P)]
+
+
+def synth_pair_device(N, M, K, d, seed, dev, dtype):
+    return synth_pairs_device(N, M, K, d, [seed], dev, dtype)[0]
 
 
 def level_sizes(N, M, max_full=300):
@@ -157,14 +163,17 @@ def e2e_host_memory(args, dev, types, W, tdt, K, N, M, d):
     from svx.vecalign import dp_utils
     pool_n, sub = args.e2e_pairs, max(1, min(args.e2e_batch, args.e2e_pairs))
     host = []
-    for i in range(pool_n):
-        a, b = synth_pair_device(N, M, K, d, 50000 + i, dev, tdt)
+    made = []
+    for i in range(0, pool_n, 16):
+        made += synth_pairs_device(N, M, K, d, [50000 + j for j in range(i, min(pool_n, i + 16))], dev, tdt)
+    for a, b in made:
         ha = torch.empty(a.shape, dtype=a.dtype, pin_memory=True)
         hb = torch.empty(b.shape, dtype=b.dtype, pin_memory=True)
         ha.copy_(a)
         hb.copy_(b)
         host.append((ha, hb))
     torch.cuda.synchronize()
+    del made
     copy_stream = torch.cuda.Stream(device=dev)
     compute = torch.cuda.current_stream(dev)
     bytes_pair = sum(x.numel() * x.element_size() for x in host[0])
@@ -379,7 +388,12 @@ def main():
         mine = balanced_shards([n + m for n, m in allshapes], world)[rank]
         shapes = [allshapes[i] for i in mine]
         seeds = [5000 + i for i in mine]
-    docs = [synth_pair_device(n, m, K, d, s, dev, tdt) for (n, m), s in zip(shapes, seeds)]
+    if args.workload == "c2":
+        docs = []
+        for i in range(0, len(seeds), 16):
+            docs += synth_pairs_device(N, M, K, d, seeds[i:i + 16], dev, tdt)
+    else:
+        docs = [synth_pair_device(n, m, K, d, s, dev, tdt) for (n, m), s in zip(shapes, seeds)]
     rngs = [np.random.RandomState(np.random.SeedSequence([2024, rank, i]).generate_state(4)) for i in range(len(docs))]
     pb = dp_utils.PreparedBatch(docs, types, 0.2, W, 300, 20000, 100, rngs=rngs, device=local)
     ctx = pb.ctx

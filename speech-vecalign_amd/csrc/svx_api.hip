@@ -636,7 +636,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         for (int depth = first_depth; depth >= 0; depth--) {
             const SvxTypes& ty = depth == 0 ? tfinal : t11;
             int lim2 = 0, tamax2 = 0;
-            const bool v2 = svxl_band2_limits(ty, W, depth, &lim2, &tamax2);  // which band-cost kernel takes this level
+            const bool v2 = svxl_band2_limits(ty, W, depth, dtype, d, &lim2, &tamax2);  // which band-cost kernel takes this level
             {
                 StageScope sc(ctx, S_PATH);
                 // (pairs whose source level has more alignment rows than the LDS holds take the kernel's serial path)

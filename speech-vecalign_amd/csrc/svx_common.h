@@ -207,7 +207,7 @@ int svxl_band_costs(svx_ctx*, const void* v0, int k0, int n, const void* v1, int
 int svxl_band_costs_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int max_A, const SvxTypes& types,
                           int W, int dtype, int d);
 // costs, second-generation band kernel of the fused pipeline (svx_band.hip)
-bool svxl_band2_limits(const SvxTypes& types, int W, int depth, int* lim, int* tamax);
+bool svxl_band2_limits(const SvxTypes& types, int W, int depth, int dtype, int d, int* lim, int* tamax);
 int svxl_band_costs2_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int max_A, const SvxTypes& types, int W,
                            int dtype, int d);
 // dp (svx_dp.hip)
