@@ -281,6 +281,97 @@ def e2e_files(args, dev, K, N, M, d):
         shutil.rmtree(root, ignore_errors=True)
 
 
+# ------------------------------------------------------------------------------------------ straight-band workloads
+def bench_straight(args):
+    """BASELINE configs[3] (`c4`: N = M = 32768, Sakoe-Chiba band 2048 around the straight diagonal, one pair per
+    step) and the dense reading of configs[1] (`dense`: N = M = 4096, every cell of the lattice, a batch of pairs per
+    step): SVX_SEARCH_STRAIGHT -- MFMA cost tiles feeding the DP as a wavefront of 32 x 32 tiles over all CUs.
+    The dominant kernel is the tile sweep; its roofline is the dense 16-bit MFMA peak (T * nodes * 2d flops)."""
+    import torch
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)
+    from svx.vecalign import dp_utils
+    K, d = args.overlaps, args.d
+    types = alignment_types(K + 1)
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    if args.workload == "c4":
+        N = M = 32768 if (args.n, args.m) == (4096, 4096) else args.n
+        W, P = args.band // 2, (args.pairs or 1)
+    else:
+        N, M = args.n, args.m
+        W, P = max(N, M) + 1, (args.pairs or 64)
+    docs = []
+    for i in range(0, P, 4):
+        docs += synth_pairs_device(N, M, K, d, [300 + 1000 * rank + j for j in range(i, min(P, i + 4))], dev, tdt)
+    rngs = [np.random.RandomState(np.random.SeedSequence([4242, rank, i]).generate_state(4)) for i in range(P)]
+    pb = dp_utils.PreparedBatch(docs, types, 0.2, W, 300, 20000, 100, rngs=rngs, device=local, search="straight")
+    ctx, lib = pb.ctx, pb.ctx.lib
+    for _ in range(args.warmup):
+        pb.run()
+    torch.cuda.synchronize()
+    lib.svx_set_profiling(ctx.h, 1)
+    names = ["pyr0", "pyr_aux", "knob_sort", "knob_scores0", "knob", "path", "tiles", "traceback", "setup", "total"]
+    ms = {k: 0.0 for k in names}
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pb.run()
+        for k in names:
+            ms[k] += lib.svx_stage_ms(ctx.h, k.encode())
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    lib.svx_set_profiling(ctx.h, 0)
+    res = pb.results()
+    ok = all([x for al in r[0] for x in al[0]] == list(range(N)) and [y for al in r[0] for y in al[1]] == list(range(M)) for r in res)
+    B = 2 * W
+    # DP nodes inside the band and the lattice: sum over node diagonals of the overlap of [bo, bo + B) with the lattice
+    nodes = 0
+    for a in range(N + M + 1):
+        yc = a * M // (N + M)
+        ylo, yhi = max(yc - W, 0, a - N), min(yc + W - 1, M, a)
+        nodes += max(0, yhi - ylo + 1)
+    flops = float(len(types)) * nodes * 2 * d
+    value = P * args.steps * world / elapsed
+    tile_ms = ms["tiles"] / args.steps
+    out = {"metric": "aligned doc-pairs/sec", "value": value, "unit": "doc-pairs/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": ("synthetic %dx%d d=%d %s, %d overlap layers/side, %d alignment types, " % (N, M, d, args.dtype, K, len(types))) +
+                                  ("Sakoe-Chiba band of %d cells around the straight diagonal" % B if args.workload == "c4" else
+                                   "dense search (band %d covers the whole lattice)" % B) + ", %d doc-pairs per GPU per step" % P,
+                      "name": args.workload, "pairs_per_step_per_gpu": P, "N": N, "M": M, "d": d, "overlaps": K, "band": B,
+                      "parallelism": "dp%d (pairs sharded, no collective)" % world},
+           "seconds_per_pair": elapsed / (P * args.steps), "dp_cells_per_pair": nodes, "dp_cells_per_s": value * nodes,
+           "alignments_cover_both_documents": bool(ok),
+           "stage_ms_per_step": {k: v / args.steps for k, v in ms.items()},
+           "roofline": {"bound": "mfma", "kernel": "k_band_tiles (cost tiles + DP wavefront)", "stage": "tiles",
+                        "achieved": flops * P / (tile_ms * 1e-3) / 1e12 if tile_ms > 0 else None, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": (flops * P / (tile_ms * 1e-3) / 1e12 / 2500.0) if tile_ms > 0 else None, "traffic": None,
+                        "avg_launch_ms": tile_ms, "algorithmic_flops_per_launch": flops * P,
+                        "note": "the sweep is bound by the serial chain of tile anti-diagonals (%d of them) and the float64 DP inside a tile, "
+                                "not by the matrix cores" % ((N // 32 + 1) + (M // 32 + 1) - 1)}}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------------ main
 def self_launch(args, argv):
     """`python bench.py --gpus N` (N > 1, not under torchrun): start N ranks as children BEFORE this process touches
@@ -303,7 +394,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "dense"])
+    ap.add_argument("--band", type=int, default=2048, help="c4: band width (cells per diagonal) around the straight diagonal")
     ap.add_argument("--pairs", type=int, default=None, help="document pairs per GPU per step (default 1024 for c2, 128 for c3)")
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--m", type=int, default=4096)
@@ -323,6 +415,8 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
+    if args.workload in ("c4", "dense"):
+        return bench_straight(args)
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

@@ -199,7 +199,20 @@ typedef struct svx_align_params {
     int32_t costs_sample_size;
     int32_t num_samps_for_norm;
     double del_percentile_frac;
+    int32_t search_mode;      /* SVX_SEARCH_* (0 = the reference's coarse-to-fine recursion) */
+    int32_t reserved0;
 } svx_align_params;
+
+/* search_mode.  COARSE_TO_FINE: dp_utils.vecalign() as the reference runs it.  STRAIGHT: the same recurrence
+ * (make_sparse_costs + sparse_dp + sparse_traceback, final alignment types, depth-0 normalisers and deletion
+ * penalty, same random draws as a vecalign() call without pyramid levels) in a band of half-width width_over2
+ * around the straight line from (0,0) to (N,M) (append_slant, dp_utils.py:177-196) instead of around an up-sampled
+ * coarse alignment: Sakoe-Chiba search (BASELINE configs[3]), and with width_over2 > max(N, M) every cell of
+ * the lattice (what vecalign() evaluates with max_size_full_dp = infinity; SURVEY.md 8a, Modes B / C).  Bands wider
+ * than 64 cells run as a wavefront of 32 x 32 tiles over all CUs, the costs of a tile computed on the matrix cores
+ * and consumed from LDS (no [T][A][B] cost tensor in memory). */
+#define SVX_SEARCH_COARSE_TO_FINE 0
+#define SVX_SEARCH_STRAIGHT 1
 
 typedef struct svx_pair {
     const void *vecs0, *vecs1; /* [k0][n][d], [k1][m][d] of params.dtype; NOT modified */
@@ -234,14 +247,15 @@ int svx_align_batch(svx_ctx *ctx, const svx_align_params *params, const svx_pair
 /* Device time of the named stage of the last svx_align_batch call, in milliseconds, measured with
  * HIP events on the context's stream when profiling is on (svx_set_profiling); one name per kernel:
  * "pyr0" "pyr1" "pyrN" "pyr_aux" "knob_sort" "knob_scores0" "knob_scoresN" "knob" "dense_costs" "dense_dp" "path"
- * "band_costs0" "band_costsN" "band_dp0" "band_dpN" "traceback" "setup" "total" (0 = level 0, N = deeper levels);
+ * "band_costs0" "band_costsN" "band_dp0" "band_dpN" "traceback" "setup" "total" (0 = level 0, N = deeper levels),
+ * "tiles" (the wide-band tile sweep of SVX_SEARCH_STRAIGHT: costs + DP);
  * "host_plan"/"host_launch" are host wall-clock.  -1 if unknown. */
 int svx_set_profiling(svx_ctx *ctx, int on);
 /* Number of internal streams svx_align_batch splits a batch over (1..4, default 1): the serial
  * kernels of one sub-batch overlap the streaming kernels of the others.  Results do not depend on it. */
 int svx_set_streams(svx_ctx *ctx, int n);
 double svx_stage_ms(svx_ctx *ctx, const char *stage);
-/* Number of launches of the dominant kernel (band_costs) in the last batch, for roofline math. */
+/* Number of launches of the named stage in the last batch. */
 int svx_stage_launches(svx_ctx *ctx, const char *stage);
 
 #ifdef __cplusplus

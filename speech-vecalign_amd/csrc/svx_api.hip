@@ -23,10 +23,10 @@ int svx_fail(svx_ctx* ctx, int code, const char* fmt, ...) {
 
 static const char* kStageNames[] = {"pyr0",       "pyrN",     "pyr_aux",      "knob_scoresN", "knob",      "dense_costs",
                                     "dense_dp",   "path",     "band_costs0",  "band_costsN",  "band_dp0",  "band_dpN",
-                                    "traceback",  "setup",    "total",        "host_plan",    "host_launch", "knob_sort", "knob_scores0", "pyr1"};
+                                    "traceback",  "setup",    "total",        "host_plan",    "host_launch", "knob_sort", "knob_scores0", "pyr1", "tiles"};
 enum {
     S_PYR0 = 0, S_PYRN, S_PYR_AUX, S_KNOB_SCORES, S_KNOB, S_DENSE_COSTS, S_DENSE_DP, S_PATH, S_BAND_COSTS0, S_BAND_COSTSN,
-    S_BAND_DP0, S_BAND_DPN, S_TRACEBACK, S_SETUP, S_TOTAL, S_HOST_PLAN, S_HOST_LAUNCH, S_KNOB_SORT, S_KNOB_SCORES0, S_PYR1, S_COUNT
+    S_BAND_DP0, S_BAND_DPN, S_TRACEBACK, S_SETUP, S_TOTAL, S_HOST_PLAN, S_HOST_LAUNCH, S_KNOB_SORT, S_KNOB_SCORES0, S_PYR1, S_TILES, S_COUNT
 };
 
 struct StageRec {
@@ -389,6 +389,12 @@ __global__ void k_init_batch(const SvxPairDev* pairs) {
         if (P.lev[l].n_align) *P.lev[l].n_align = 0;
         if (P.lev[l].path_len) *P.lev[l].path_len = 0;
     }
+    if (P.straight) {
+        // the straight search path is the slant of ONE alignment block covering both documents (dp_utils.py:177-225)
+        int* r = P.lev[0].align;
+        r[0] = 0; r[1] = P.lev[0].n[0]; r[2] = 0; r[3] = P.lev[0].n[1];
+        *P.lev[0].n_align = 1;
+    }
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -415,12 +421,21 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
     int mx = 0, my = 0;
     for (int t = 0; t < tfinal.n; t++) { if (tfinal.x[t] > mx) mx = tfinal.x[t]; if (tfinal.y[t] > my) my = tfinal.y[t]; }
     const bool packable = mx <= 15 && my <= 15;  // back-pointers fit 4 bits each
+    NEED(ctx, prm->search_mode == SVX_SEARCH_COARSE_TO_FINE || prm->search_mode == SVX_SEARCH_STRAIGHT, "svx_align_batch: unknown search_mode %d", prm->search_mode);
+    const bool straight = prm->search_mode == SVX_SEARCH_STRAIGHT;
+    // straight search with a band wider than the one-workgroup DP kernel takes: wavefront of tiles (svx_tiles.hip)
+    const bool tiles = straight && B > 64;
+    if (tiles) {
+        NEED(ctx, packable && tfinal.n >= 1 && svxl_band_tiles_ok(tfinal),
+             "wide straight band: the tile kernel takes 1..16 alignment types on <= 12 overlap layers with steps <= 8");
+    }
 
     // ---- plan: level sizes, scratch layout, launch extents
     std::vector<SvxPairDev>& host = cx->host;
     host.assign(n_pairs, SvxPairDev());
     Bump bump;
     const size_t o_desc = bump.take((size_t)n_pairs * sizeof(SvxPairDev));
+    const size_t o_tickets = bump.take((size_t)(n_pairs + 2) * sizeof(int));  // pair_pref [n_pairs + 1], ticket
     int maxL = 0, max_ksum = 0, max_kn = 0, max_ds0 = 0, max_ds1 = 0, max_n0 = 0;
     int max_nblk[SVX_MAX_LEVELS] = {0}, max_A[SVX_MAX_LEVELS] = {0};
     bool any_L0 = false;
@@ -434,7 +449,8 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         NEED(ctx, in.n >= 1 && in.m >= 1 && in.k0 >= 1 && in.k1 >= 1, "pair %d: empty document or no overlap layers", p);
         if (mx > in.k0) return svx_fail(ctx, SVX_ERR_OVERLAPS, "%d x overlaps requrested (via alignment_types), but vecs0 only has %d", mx, in.k0);
         if (my > in.k1) return svx_fail(ctx, SVX_ERR_OVERLAPS, "%d y overlaps requrested (via alignment_types), but vecs1 only has %d", my, in.k1);
-        const int L = svx_num_levels(in.n, in.m, prm->max_size_full_dp);
+        const int L = straight ? 0 : svx_num_levels(in.n, in.m, prm->max_size_full_dp);
+        P.straight = straight ? 1 : 0;
         NEED(ctx, L < SVX_MAX_LEVELS, "pair %d: %d pyramid levels (max %d)", p, L + 1, SVX_MAX_LEVELS);
         P.v[0] = in.vecs0; P.v[1] = in.vecs1;
         P.K[0] = in.k0; P.K[1] = in.k1;
@@ -506,7 +522,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
                 OFF(Lv.path_len, sizeof(int));
                 OFF(Lv.cstart, (size_t)(cap / 16 + 3) * sizeof(int));  // a chunk holds at least 17 path points
                 OFF(Lv.nchunks, sizeof(int));
-                OFF(Lv.costs, (size_t)(T > 0 ? T : 1) * cap * B * sizeof(float));
+                if (!tiles) OFF(Lv.costs, (size_t)(T > 0 ? T : 1) * cap * B * sizeof(float));  // (the tile sweep keeps costs in LDS)
                 OFF(Lv.boff, (size_t)cap * sizeof(int));
                 OFF(Lv.csum, (size_t)(cap + 2) * B * sizeof(double));
                 if (packable) {
@@ -528,11 +544,25 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             }
         }
         const SvxLevel& top = P.lev[L];
-        if (top.n[0] > max_ds0) max_ds0 = top.n[0];
-        if (top.n[1] > max_ds1) max_ds1 = top.n[1];
-        OFF(P.dcost, (size_t)top.n[0] * top.n[1] * sizeof(float));
-        OFF(P.ddot, (size_t)top.n[0] * top.n[1] * sizeof(float));
-        OFF(P.dbp, (size_t)(top.n[0] + top.n[1] + 1) * (top.n[0] + 1) * sizeof(int));  // (anti-diagonal, row) layout
+        if (!straight) {
+            if (top.n[0] > max_ds0) max_ds0 = top.n[0];
+            if (top.n[1] > max_ds1) max_ds1 = top.n[1];
+            OFF(P.dcost, (size_t)top.n[0] * top.n[1] * sizeof(float));
+            OFF(P.ddot, (size_t)top.n[0] * top.n[1] * sizeof(float));
+            OFF(P.dbp, (size_t)(top.n[0] + top.n[1] + 1) * (top.n[0] + 1) * sizeof(int));  // (anti-diagonal, row) layout
+        }
+        if (tiles) {
+            const long long TI = in.n / 32 + 1, TJ = in.m / 32 + 1;  // tiles of 32 x 32 nodes over (n + 1) x (m + 1)
+            P.t_nd = (int)(TI + TJ - 1);
+            long long tcap = (long long)P.t_nd * ((B + 64) / 32 + 2);
+            if (tcap > TI * TJ) tcap = TI * TJ;
+            NEED(ctx, tcap < (1ll << 30), "pair %d: too many tiles", p);
+            P.t_cap = (int)tcap;
+            OFF(P.t_lo, (size_t)P.t_nd * sizeof(int));
+            OFF(P.t_cnt, (size_t)P.t_nd * sizeof(int));
+            OFF(P.t_pref, (size_t)(P.t_nd + 1) * sizeof(int));
+            OFF(P.t_flag, (size_t)P.t_cap * sizeof(int));
+        }
     }
 #undef OFF
     if ((rc = arena_reserve(ctx, bump.off))) return rc;
@@ -562,6 +592,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         patch(P.dcost);
         patch(P.ddot);
         patch(P.dbp);
+        patch(P.t_lo); patch(P.t_cnt); patch(P.t_pref); patch(P.t_flag);
     }
     SvxPairDev* dpairs = reinterpret_cast<SvxPairDev*>(base + o_desc);
     hipStream_t st = ctx->stream;
@@ -607,7 +638,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             StageScope sc(ctx, l == 0 ? S_PYR0 : (l == 1 ? S_PYR1 : S_PYRN));
             if ((rc2 = svxl_pyramid_level(ctx, dp, np, l, dtype, d, max_nblk[l], max_ksum, 1))) return rc2;
         }
-        {
+        if (!straight) {
             // coarsest level: the dense 1-1 cost matrix, and with it the dot products its sampled scores need
             StageScope sc(ctx, S_DENSE_COSTS);
             if ((rc2 = svxl_dense_costs_batch(ctx, dp, np, max_ds0, max_ds1, dtype, d))) return rc2;
@@ -628,7 +659,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             StageScope sc(ctx, S_KNOB);
             if ((rc2 = svxl_del_penalty_batch(ctx, dp, np, maxL + 1, prm->del_percentile_frac))) return rc2;
         }
-        {
+        if (!straight) {
             StageScope sc(ctx, S_DENSE_DP);
             if ((rc2 = svxl_dense_stage_batch(ctx, dp, np, max_ds0))) return rc2;
         }
@@ -636,7 +667,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         for (int depth = first_depth; depth >= 0; depth--) {
             const SvxTypes& ty = depth == 0 ? tfinal : t11;
             int lim2 = 0, tamax2 = 0;
-            const bool v2 = svxl_band2_limits(ty, W, depth, dtype, d, &lim2, &tamax2);  // which band-cost kernel takes this level
+            const bool v2 = !tiles && svxl_band2_limits(ty, W, depth, dtype, d, &lim2, &tamax2);  // which band-cost kernel takes this level
             {
                 StageScope sc(ctx, S_PATH);
                 // (pairs whose source level has more alignment rows than the LDS holds take the kernel's serial path)
@@ -644,15 +675,21 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
                 if ((rc2 = svxl_search_path_batch(ctx, dp, np, depth, max_A[depth], src_rows, v2 ? lim2 : SVX_BC_ROWS - SVX_BC_TB,
                                                   v2 ? tamax2 : SVX_BC_TAMAX))) return rc2;
             }
-            {
-                StageScope sc(ctx, depth == 0 ? S_BAND_COSTS0 : S_BAND_COSTSN);
-                if (v2) rc2 = svxl_band_costs2_batch(ctx, dp, np, depth, max_A[depth], ty, W, dtype, d);
-                else rc2 = svxl_band_costs_batch(ctx, dp, np, depth, max_A[depth], ty, W, dtype, d);
-                if (rc2) return rc2;
-            }
-            {
-                StageScope sc(ctx, depth == 0 ? S_BAND_DP0 : S_BAND_DPN);
-                if ((rc2 = svxl_sparse_dp_batch(ctx, dp, np, depth, ty, B))) return rc2;
+            if (tiles) {
+                StageScope sc(ctx, S_TILES);
+                int* tk = reinterpret_cast<int*>(base + o_tickets) + (dp - dpairs);  // (sub-batches use disjoint slices)
+                if ((rc2 = svxl_band_tiles_batch(ctx, dp, np, ty, W, dtype, tk, tk + np + 1))) return rc2;
+            } else {
+                {
+                    StageScope sc(ctx, depth == 0 ? S_BAND_COSTS0 : S_BAND_COSTSN);
+                    if (v2) rc2 = svxl_band_costs2_batch(ctx, dp, np, depth, max_A[depth], ty, W, dtype, d);
+                    else rc2 = svxl_band_costs_batch(ctx, dp, np, depth, max_A[depth], ty, W, dtype, d);
+                    if (rc2) return rc2;
+                }
+                {
+                    StageScope sc(ctx, depth == 0 ? S_BAND_DP0 : S_BAND_DPN);
+                    if ((rc2 = svxl_sparse_dp_batch(ctx, dp, np, depth, ty, B))) return rc2;
+                }
             }
             {
                 StageScope sc(ctx, S_TRACEBACK);

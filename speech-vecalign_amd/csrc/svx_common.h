@@ -148,6 +148,13 @@ struct SvxPairDev {
     float* ddot;       // [s0][s1] raw dot products of the same stage (L >= 1): the level's sampled scores read them
     int* dbp;          // [s0+s1+1][s0+1]: back-pointers of the dense stage by (anti-diagonal, row)
     int* status;       // info[1]
+    // straight-band search with the tile sweep (svx_tiles.hip): per tile anti-diagonal s the run of band tiles
+    int straight;
+    int t_nd, t_cap;   // tile anti-diagonals; capacity of t_flag
+    int* t_lo;         // [t_nd] first tile row I of diagonal s
+    int* t_cnt;        // [t_nd]
+    int* t_pref;       // [t_nd + 1] tiles before diagonal s
+    int* t_flag;       // [t_cap] tile finished
     SvxLevel lev[SVX_MAX_LEVELS];
 };
 
@@ -210,6 +217,10 @@ int svxl_band_costs_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int de
 bool svxl_band2_limits(const SvxTypes& types, int W, int depth, int dtype, int d, int* lim, int* tamax);
 int svxl_band_costs2_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int max_A, const SvxTypes& types, int W,
                            int dtype, int d);
+// wide bands as a wavefront of tiles (svx_tiles.hip)
+bool svxl_band_tiles_ok(const SvxTypes& types);
+int svxl_band_tiles_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, const SvxTypes& types, int W, int dtype, int* pair_pref,
+                          int* ticket);
 // dp (svx_dp.hip)
 int svxl_dense_dp(svx_ctx*, const float* cost, int s0, int s1, float pen, double* csum, int* bp);
 int svxl_dense_stage_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_s0);

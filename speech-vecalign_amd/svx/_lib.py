@@ -11,6 +11,7 @@ SVX_F32, SVX_F16, SVX_BF16 = 0, 1, 2
 SVX_MAX_TYPES = 128
 SVX_MAX_LEVELS = 16
 SVX_MARGIN_RATIO, SVX_MARGIN_DISTANCE = 0, 1
+SVX_SEARCH_COARSE_TO_FINE, SVX_SEARCH_STRAIGHT = 0, 1
 
 SVX_OK, SVX_ERR_ARG, SVX_ERR_OVERLAPS, SVX_ERR_HIP, SVX_ERR_TRACEBACK = 0, 1, 2, 3, 4
 SVX_ERR_NOMEM, SVX_ERR_EXTEND, SVX_ERR_PATH, SVX_ERR_BP = 5, 6, 7, 8
@@ -37,6 +38,8 @@ class AlignParams(ctypes.Structure):
         ("costs_sample_size", ctypes.c_int32),
         ("num_samps_for_norm", ctypes.c_int32),
         ("del_percentile_frac", ctypes.c_double),
+        ("search_mode", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
     ]
 
 

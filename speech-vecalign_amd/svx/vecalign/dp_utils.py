@@ -158,7 +158,14 @@ class PreparedBatch:
     is built here once."""
 
     def __init__(self, pairs, final_alignment_types, del_percentile_frac, width_over2, max_size_full_dp,
-                 costs_sample_size, num_samps_for_norm, rngs=None, norms=None, device=None):
+                 costs_sample_size, num_samps_for_norm, rngs=None, norms=None, device=None, search="coarse_to_fine"):
+        """search: "coarse_to_fine" (the reference's recursion) or "straight" (band of half-width `width_over2`
+        around the straight line from (0,0) to (N,M): Sakoe-Chiba / dense search, include/svx.h SVX_SEARCH_STRAIGHT;
+        no pyramid, so `max_size_full_dp` is ignored)."""
+        if search not in ("coarse_to_fine", "straight"):
+            raise ValueError("search must be 'coarse_to_fine' or 'straight'")
+        if search == "straight":
+            max_size_full_dp = 1 << 30  # depth 0 only: the random draws of a vecalign() call without pyramid levels
         ctx = _lib.context(device)
         self.ctx = ctx
         t = ctx.torch
@@ -192,6 +199,7 @@ class PreparedBatch:
         prm.costs_sample_size = int(costs_sample_size)
         prm.num_samps_for_norm = int(num_samps_for_norm)
         prm.del_percentile_frac = float(del_percentile_frac)
+        prm.search_mode = _lib.SVX_SEARCH_STRAIGHT if search == "straight" else _lib.SVX_SEARCH_COARSE_TO_FINE
         self.prm = prm
         npairs = len(self.vecs)
         self.cpairs = (_lib.Pair * npairs)()
@@ -299,12 +307,12 @@ class PreparedBatch:
 
 
 def align_batch(pairs, final_alignment_types, del_percentile_frac, width_over2, max_size_full_dp,
-                costs_sample_size, num_samps_for_norm, rngs=None, norms=None, device=None):
+                costs_sample_size, num_samps_for_norm, rngs=None, norms=None, device=None, search="coarse_to_fine"):
     """vecalign() for a list of (vecs0, vecs1) pairs in one device pass.
     rngs: optional per-pair numpy RandomState objects (shard-invariant sampling); default = the
     global numpy stream consumed pair after pair, exactly like the reference's serial loop."""
     pb = PreparedBatch(pairs, final_alignment_types, del_percentile_frac, width_over2, max_size_full_dp,
-                       costs_sample_size, num_samps_for_norm, rngs=rngs, norms=norms, device=device)
+                       costs_sample_size, num_samps_for_norm, rngs=rngs, norms=norms, device=device, search=search)
     pb.run()
     return pb.results()
 
@@ -476,74 +484,22 @@ def alignment_to_search_path(algn):
 
 # ------------------------------------------------------------------------------------- Sakoe-Chiba mode
 def align_band(vecs0, vecs1, final_alignment_types, del_percentile_frac, width_over2, costs_sample_size,
-               num_samps_for_norm):
-    """Banded alignment around the straight diagonal (Sakoe-Chiba, BASELINE.json configs[3]): the same
-    recurrence as the refinement step of vecalign() -- make_sparse_costs + sparse_dp + sparse_traceback
-    (dp_core.pyx:165-404, dp_utils.py:105-143) with the final alignment types -- but the search path is
-    the straight line from (0,0) to (N,M) (append_slant, dp_utils.py:177-196) with band half-width
-    `width_over2` instead of an up-sampled coarse alignment.  Norms and the deletion penalty are those of
-    depth 0 of vecalign() (same random draws, same order).  float32 inputs [K, N, d]; every step is a
-    C-ABI call on device-resident tensors.  Returns (alignments, scores)."""
-    ctx = _ctx()
-    t = ctx.torch
-    lib = ctx.lib
-    v0 = _dev(ctx, vecs0).float().clone()
-    v1 = _dev(ctx, vecs1).float().clone()
-    k0, n, d = (int(x) for x in v0.shape)
-    k1, m, _ = (int(x) for x in v1.shape)
-    ctx.check(lib.svx_make_norm1(ctx.h, _p(v0), k0 * n, d))
-    ctx.check(lib.svx_make_norm1(ctx.h, _p(v1), k1 * m, d))
+               num_samps_for_norm, rng=None):
+    """Banded alignment around the straight diagonal (Sakoe-Chiba, BASELINE.json configs[3]; with
+    width_over2 > max(N, M) the dense mode): the same recurrence as the refinement step of vecalign() --
+    make_sparse_costs + sparse_dp + sparse_traceback (dp_core.pyx:165-404, dp_utils.py:105-143) with the final
+    alignment types -- but the search path is the straight line from (0,0) to (N,M) (append_slant,
+    dp_utils.py:177-196) with band half-width `width_over2` instead of an up-sampled coarse alignment.  Norms and
+    the deletion penalty are those of depth 0 of vecalign() (same random draws, same order).  One svx_align_batch
+    call (SVX_SEARCH_STRAIGHT): bands wider than 64 cells run as a wavefront of MFMA cost tiles + DP over all
+    CUs.  Inputs of any storage type ([K, N, d] float32 / float16 / bfloat16).  Returns (alignments, scores)."""
+    res = align_band_batch([(vecs0, vecs1)], final_alignment_types, del_percentile_frac, width_over2, costs_sample_size,
+                           num_samps_for_norm, rngs=None if rng is None else [rng])
+    return res[0][0], res[0][1]
 
-    def norms(a, ka, na, b, kb, nb):
-        spo = ceil(num_samps_for_norm / kb)
-        out = t.ones((ka, na), dtype=t.float32, device=ctx.tdev)
-        if nb and spo:
-            idx = np.stack([np.random.choice(nb, size=spo, replace=True) for _ in range(kb)]).astype(np.int32)
-            di = _dev(ctx, idx)
-            ctx.check(lib.svx_compute_norms(ctx.h, _p(a), ka, na, _p(b), kb, nb, d, _p(di), spo, _p(out)))
-        return out
-    n0 = norms(v0, k0, n, v1, k1, m)
-    n1 = norms(v1, k1, m, v0, k0, n)
-    if n * m < costs_sample_size:
-        xs = np.repeat(np.arange(n, dtype=np.int32), m)
-        ys = np.tile(np.arange(m, dtype=np.int32), n)
-    else:
-        xs = np.random.choice(n, size=costs_sample_size, replace=True).astype(np.int32)
-        ys = np.random.choice(m, size=costs_sample_size, replace=True).astype(np.int32)
-    dx, dy = _dev(ctx, xs), _dev(ctx, ys)
-    sc = t.empty(len(xs), dtype=t.float32, device=ctx.tdev)
-    ctx.check(lib.svx_score_path(ctx.h, _p(dx), _p(dy), len(xs), _p(n0[0]), _p(n1[0]), _p(v0[0]), n, _p(v1[0]), m, d, _p(sc)))
-    pen = t.zeros(1, dtype=t.float64, device=ctx.tdev)
-    ctx.check(lib.svx_del_penalty(ctx.h, _p(sc), len(xs), float(del_percentile_frac), _p(pen)))
-    # straight search path = one slant over the whole pair
-    rows = _dev(ctx, np.array([[0, n, 0, m]], dtype=np.int32))
-    na = _dev(ctx, np.array([1], dtype=np.int32))
-    path = t.zeros((n + m + 4, 2), dtype=t.int32, device=ctx.tdev)
-    plen = t.zeros(1, dtype=t.int32, device=ctx.tdev)
-    ctx.check(lib.svx_search_path(ctx.h, _p(rows), _p(na), 0, n, m, _p(path), _p(plen)))
-    A = int(plen.cpu().numpy()[0])
-    if A < 0:
-        raise Exception('search path failure %d' % -A)
-    types = [tuple(int(v) for v in xy) for xy in final_alignment_types]
-    flat = [v for xy in types for v in xy]
-    ctypes_types = (ctypes.c_int32 * max(1, len(flat)))(*flat)
-    T, W = len(types), int(width_over2)
-    B = 2 * W
-    costs = t.empty((max(T, 1), A, B), dtype=t.float32, device=ctx.tdev)
-    boff = t.empty(A, dtype=t.int32, device=ctx.tdev)
-    ctx.check(lib.svx_sparse_costs(ctx.h, _p(v0), k0, n, _p(v1), k1, m, d, _p(n0), _p(n1), _p(path), A, ctypes_types, T, W,
-                                   _p(costs), _p(boff)))
-    csum = t.empty((A + 2, B), dtype=t.float64, device=ctx.tdev)
-    xp = t.empty((A + 2, B), dtype=t.int32, device=ctx.tdev)
-    yp = t.empty((A + 2, B), dtype=t.int32, device=ctx.tdev)
-    bout = t.empty(A + 2, dtype=t.int32, device=ctx.tdev)
-    ctx.check(lib.svx_sparse_dp(ctx.h, _p(costs), _p(boff), A, B, ctypes_types, T, float(pen.cpu().numpy()[0]), n, m,
-                                _p(csum), _p(xp), _p(yp), _p(bout)))
-    al = t.zeros((n + m + 2, 4), dtype=t.int32, device=ctx.tdev)
-    scores = t.zeros(n + m + 2, dtype=t.float64, device=ctx.tdev)
-    cnt = t.zeros(1, dtype=t.int32, device=ctx.tdev)
-    ctx.check(lib.svx_sparse_traceback(ctx.h, _p(csum), _p(xp), _p(yp), _p(bout), A + 2, B, n, m, _p(al), _p(scores), _p(cnt)))
-    c = int(cnt.cpu().numpy()[0])
-    if c < 0:
-        raise Exception('traceback bug')
-    return rows_to_alignments(al.cpu().numpy()[:c]), scores.cpu().numpy()[:c].copy()
+
+def align_band_batch(pairs, final_alignment_types, del_percentile_frac, width_over2, costs_sample_size, num_samps_for_norm,
+                     rngs=None, device=None):
+    """align_band() for a list of pairs in one device pass -> [(alignments, scores, [del_penalty])]."""
+    return align_batch(pairs, final_alignment_types, del_percentile_frac, width_over2, 1 << 30, costs_sample_size,
+                       num_samps_for_norm, rngs=rngs, device=device, search="straight")

@@ -32,7 +32,7 @@ def test_host_side_helpers_without_gpu():
     assert lib.svx_knob_count(90, 80, 20000) == 7200
     assert lib.svx_knob_count(4096, 4096, 20000) == 20000
     # struct layout agreed between ctypes and the header (sizes only; offsets are natural alignment)
-    assert ctypes.sizeof(_lib.AlignParams) == 4 * 3 + 4 * 256 + 4 * 4 + 4 + 8
+    assert ctypes.sizeof(_lib.AlignParams) == 4 * 3 + 4 * 256 + 4 * 4 + 4 + 8 + 2 * 4  # (+ search_mode, reserved0)
     assert ctypes.sizeof(_lib.Pair) == 8 * 2 + 4 * 4 + 8 * 8
 
 

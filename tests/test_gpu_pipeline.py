@@ -196,6 +196,63 @@ def test_dense_mode_vs_oracle(orc):
     assert st[0]['final_alignments'] == al_g
 
 
+def _straight_oracle(orc, v0, v1, types, W, seed):
+    """make_sparse_costs + sparse_dp + sparse_traceback on the straight path, depth-0 norms and penalty (oracle)."""
+    N, M = v0.shape[1], v1.shape[1]
+    a, b = v0.copy(), v1.copy()
+    orc.make_norm1(a)
+    orc.make_norm1(b)
+    rs = np.random.RandomState(seed)
+    n0, n1 = orc.compute_norms(a, b, 100, rs), orc.compute_norms(b, a, 100, rs)
+    pen, _ = orc.make_del_penalty(a[0], b[0], n0[0], n1[0], 20000, 0.2, rs)
+    path = orc.search_path([(list(range(N)), list(range(M)))], False, N, M)
+    f, bo = orc.make_sparse_costs(a, b, n0, n1, path, types, W)
+    return orc.sparse_traceback(*orc.sparse_dp(f, bo, types, pen, N, M), N, M)
+
+
+@pytest.mark.parametrize("case", [
+    dict(N=700, M=640, K=4, a=5, d=1024, W=40, dt="bf16", dels=20),     # tile sweep, bf16 d = 1024, 10 types
+    dict(N=333, M=421, K=4, a=5, d=1024, W=422, dt="f16", dels=11),     # dense mode (band covers the lattice), fp16
+    dict(N=260, M=250, K=5, a=6, d=64, W=50, dt="f32", dels=9),         # 15 types on 10 layers (second tile shape), fp32 rows
+    dict(N=97, M=1000, K=3, a=4, d=64, W=45, dt="f32", dels=0),         # very uneven documents: steep straight path
+    dict(N=500, M=480, K=4, a=5, d=96, W=33, dt="bf16", dels=15, zero=30),  # d not a multiple of 32 (tail slab), zero rows: exact ties
+])
+def test_straight_band_tiles_vs_oracle(orc, case):
+    """SVX_SEARCH_STRAIGHT with bands wider than 64 cells (the tile sweep of csrc/svx_tiles.hip) against the oracle's
+    make_sparse_costs / sparse_dp / sparse_traceback on the same straight path: identical spans, scores within 1e-4."""
+    import torch
+    from svx.vecalign import dp_utils
+    c = case
+    v0, v1 = make_pair(c["N"], c["M"], c["K"], c["d"], 400 + c["N"], deletions=c["dels"], zero_rows=c.get("zero", 0))
+    if c["dt"] == "bf16":
+        v0, v1 = round_bf16(v0), round_bf16(v1)
+    elif c["dt"] == "f16":
+        v0, v1 = v0.astype(np.float16).astype(np.float32), v1.astype(np.float16).astype(np.float32)
+    types = alignment_types(c["a"])
+    al_o, sc_o = _straight_oracle(orc, v0, v1, types, c["W"], 31)
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[c["dt"]]
+    np.random.seed(31)
+    al_g, sc_g = dp_utils.align_band(torch.from_numpy(v0).cuda().to(tdt), torch.from_numpy(v1).cuda().to(tdt), types, 0.2, c["W"], 20000, 100)
+    assert al_g == al_o
+    assert np.abs(sc_g - sc_o).max() < SCORE_TOL
+
+
+def test_straight_band_batch_is_batch_invariant():
+    """Several pairs of different sizes in one tile sweep (tickets run over pairs): every pair equals its own run."""
+    from svx.vecalign import dp_utils
+    types = alignment_types(5)
+    shapes = [(300, 280), (90, 500), (640, 700), (33, 31)]
+    docs = [make_pair(n, m, 4, 64, 900 + i, deletions=5) for i, (n, m) in enumerate(shapes)]
+    mk = lambda i: np.random.RandomState(70 + i)
+    batch = dp_utils.align_band_batch(docs, types, 0.2, 40, 20000, 100, rngs=[mk(i) for i in range(len(docs))])
+    for i in range(len(docs)):
+        single = dp_utils.align_band_batch([docs[i]], types, 0.2, 40, 20000, 100, rngs=[mk(i)])[0]
+        assert single[0] == batch[i][0] and np.array_equal(single[1], batch[i][1])
+        xs = [x for al in batch[i][0] for x in al[0]]
+        ys = [y for al in batch[i][0] for y in al[1]]
+        assert xs == list(range(shapes[i][0])) and ys == list(range(shapes[i][1]))
+
+
 def test_sakoe_chiba_full_size_equals_coarse_to_fine():
     """BASELINE configs[3] at full size -- N = M = 32768, d = 1024, band 2048 around the straight diagonal
     (no CPU implementation finishes this in test time: 2.7e9 cost cells).  Size-independent property instead:
