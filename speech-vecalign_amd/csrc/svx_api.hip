@@ -435,7 +435,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
     host.assign(n_pairs, SvxPairDev());
     Bump bump;
     const size_t o_desc = bump.take((size_t)n_pairs * sizeof(SvxPairDev));
-    const size_t o_tickets = bump.take((size_t)(n_pairs + 2) * sizeof(int));  // pair_pref [n_pairs + 1], ticket
+    size_t o_tickets = 0;  // wide straight bands: ticket table [tile anti-diagonals x pairs + 1] and the ticket counter (below)
     int maxL = 0, max_ksum = 0, max_kn = 0, max_ds0 = 0, max_ds1 = 0, max_n0 = 0;
     int max_nblk[SVX_MAX_LEVELS] = {0}, max_A[SVX_MAX_LEVELS] = {0};
     bool any_L0 = false;
@@ -565,6 +565,10 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         }
     }
 #undef OFF
+    int max_tnd = 0;
+    for (int p = 0; p < n_pairs; p++)
+        if (host[p].t_nd > max_tnd) max_tnd = host[p].t_nd;
+    if (tiles) o_tickets = bump.take(((size_t)(max_tnd + 2) * n_pairs + 2) * sizeof(int));
     if ((rc = arena_reserve(ctx, bump.off))) return rc;
     // patch offsets (+1) into device pointers
     char* base = ctx->arena;
@@ -673,12 +677,13 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
                 // (pairs whose source level has more alignment rows than the LDS holds take the kernel's serial path)
                 const int src_rows = (maxL > 0 && !any_L0) ? max_A[depth] / 2 + 8 : max_A[depth];
                 if ((rc2 = svxl_search_path_batch(ctx, dp, np, depth, max_A[depth], src_rows, v2 ? lim2 : SVX_BC_ROWS - SVX_BC_TB,
-                                                  v2 ? tamax2 : SVX_BC_TAMAX))) return rc2;
+                                                  tiles ? 0 : (v2 ? tamax2 : SVX_BC_TAMAX)))) return rc2;
             }
             if (tiles) {
                 StageScope sc(ctx, S_TILES);
-                int* tk = reinterpret_cast<int*>(base + o_tickets) + (dp - dpairs);  // (sub-batches use disjoint slices)
-                if ((rc2 = svxl_band_tiles_batch(ctx, dp, np, ty, W, dtype, tk, tk + np + 1))) return rc2;
+                // (sub-batches on their own streams use disjoint slices of the ticket region)
+                int* tk = reinterpret_cast<int*>(base + o_tickets) + (size_t)max_tnd * (dp - dpairs) + 2 * (dp - dpairs);
+                if ((rc2 = svxl_band_tiles_batch(ctx, dp, np, ty, W, dtype, max_tnd, tk, tk + (size_t)max_tnd * np + 1))) return rc2;
             } else {
                 {
                     StageScope sc(ctx, depth == 0 ? S_BAND_COSTS0 : S_BAND_COSTSN);

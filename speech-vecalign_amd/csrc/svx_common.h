@@ -219,8 +219,8 @@ int svxl_band_costs2_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int d
                            int dtype, int d);
 // wide bands as a wavefront of tiles (svx_tiles.hip)
 bool svxl_band_tiles_ok(const SvxTypes& types);
-int svxl_band_tiles_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, const SvxTypes& types, int W, int dtype, int* pair_pref,
-                          int* ticket);
+int svxl_band_tiles_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, const SvxTypes& types, int W, int dtype, int max_nd,
+                          int* gpref, int* ticket);
 // dp (svx_dp.hip)
 int svxl_dense_dp(svx_ctx*, const float* cost, int s0, int s1, float pen, double* csum, int* bp);
 int svxl_dense_stage_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_s0);
@@ -234,6 +234,6 @@ int svxl_sparse_traceback_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, 
 int svxl_search_path(svx_ctx*, const int* align, const int* n_align, int upsample, int size0, int size1, int* path,
                      int cap, int* path_len);
 int svxl_search_path_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int depth, int max_rows, int max_src_rows, int chunk_lim,
-                           int chunk_tamax);
+                           int chunk_tamax);  // chunk_tamax <= 0: no band-cost chunks wanted
 int svxl_del_penalty(svx_ctx*, const float* scores, int64_t n, double frac, double* out);
 int svxl_del_penalty_batch(svx_ctx*, const SvxPairDev* pairs, int n_pairs, int max_levels, double frac);

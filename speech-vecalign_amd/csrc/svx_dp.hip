@@ -644,6 +644,9 @@ struct TbArgs {
     int* count;
     int* status;
     int chunk;                 // > 0: diagonals per LDS window (two windows of back-pointers + b_offset_out); 0: walk global memory
+    int cw;                    // > 0 (packed back-pointers, wide bands): a window holds only `cw` columns of each diagonal, a
+                               // corridor centred on the walk's column when the window before it was entered (the column moves by
+                               // at most one per diagonal, so the walk stays inside; a step that does not reads global memory)
 };
 
 // One LDS window = `chunk` diagonals of back-pointers (bytes from bpk, or 16-bit words packed from xp/yp) and
@@ -652,6 +655,7 @@ __host__ __device__ inline size_t tb_win_bytes(int chunk, int B, bool wide) {
     const size_t bp = (size_t)chunk * B * (wide ? 2 : 1);
     return ((bp + 15) & ~(size_t)15) + (size_t)chunk * sizeof(int);
 }
+constexpr int TB_COR_CHUNK = 64, TB_COR_W = 320;  // corridor windows: 64 diagonals x 320 columns (drift <= 2 x 64 each way)
 __host__ __device__ inline size_t tb_smem_bytes(int chunk, int B, bool wide) { return 2 * tb_win_bytes(chunk, B, wide); }
 // diagonals per window: a multiple of 16 (so that a window of bytes starts 16-byte aligned) within ~20 KB
 __host__ __device__ inline int tb_chunk(int B, bool wide) {
@@ -660,6 +664,21 @@ __host__ __device__ inline int tb_chunk(int B, bool wide) {
 }
 
 // window j = diagonals [j*chunk, min((j+1)*chunk, Aout)) -> LDS
+// corridor window j: columns [c0, c0 + cw) of diagonals [j*chunk, (j+1)*chunk), row stride cw bytes.  c0 and cw are
+// multiples of 16 and the corridor lies inside [0, B) (B a multiple of 16): rows move as 16-byte pieces.
+__device__ __forceinline__ void tb_load_corridor(const TbArgs& g, char* win, int j, int c0, int tsub, int nsub) {
+    const int lo = j * g.chunk;
+    const int hi = (lo + g.chunk) < g.Aout ? (lo + g.chunk) : g.Aout;
+    int* lbo = reinterpret_cast<int*>(win + ((((size_t)g.chunk * g.cw) + 15) & ~(size_t)15));
+    for (int i = tsub; i < hi - lo; i += nsub) lbo[i] = g.boff[lo + i];
+    const int ppr = g.cw / 16;  // pieces per row
+    const int n = (hi - lo) * ppr;
+    for (int e = tsub; e < n; e += nsub) {
+        const int i = e / ppr, p = e - i * ppr;
+        reinterpret_cast<uint4*>(win)[e] = *reinterpret_cast<const uint4*>(g.bpk + (size_t)(lo + i) * g.B + c0 + 16 * p);
+    }
+}
+
 __device__ __forceinline__ void tb_load_window(const TbArgs& g, char* win, int j, int tsub, int nsub) {
     const int B = g.B, lo = j * g.chunk;
     const int hi = (lo + g.chunk) < g.Aout ? (lo + g.chunk) : g.Aout;
@@ -691,25 +710,51 @@ __device__ __forceinline__ void tb_load_window(const TbArgs& g, char* win, int j
 // pair of windows: while thread 0 walks window j the other waves fetch window j-1.
 __device__ void sparse_traceback_block(const TbArgs& g, char* smem) {
     __shared__ int sh_n;
+    __shared__ int sh_c0[2];   // corridor windows: first column of the window in buffer 0 / 1
     const int cap = g.xs + g.ys + 2;
     const int Aout = g.Aout, B = g.B;
     const bool wide = g.bpk == nullptr;
-    const size_t win_bytes = g.chunk > 0 ? tb_win_bytes(g.chunk, B, wide) : 0;
+    const bool cor = g.cw > 0;
+    const size_t win_bytes = g.chunk > 0 ? (cor ? tb_win_bytes(g.chunk, g.cw, false) : tb_win_bytes(g.chunk, B, wide)) : 0;
     const int nwin = g.chunk > 0 ? (Aout + g.chunk - 1) / g.chunk : 1;
     int xx = g.xs, yy = g.ys, nw = 0, err = 0;  // walk state of thread 0
     bool done = false;
     if (g.chunk > 0) {
-        tb_load_window(g, smem + (size_t)((nwin - 1) & 1) * win_bytes, nwin - 1, threadIdx.x, blockDim.x);
+        if (cor) {
+            const int aa = g.xs + g.ys;
+            const int b_end = (aa >= 0 && aa < Aout) ? g.ys - g.boff[aa] : 0;
+            if (threadIdx.x == 0) {
+                int c = (b_end - g.cw / 2) & ~15;
+                c = c < 0 ? 0 : (c > B - g.cw ? B - g.cw : c);
+                sh_c0[(nwin - 1) & 1] = c;
+            }
+            __syncthreads();
+            tb_load_corridor(g, smem + (size_t)((nwin - 1) & 1) * win_bytes, nwin - 1, sh_c0[(nwin - 1) & 1], threadIdx.x, blockDim.x);
+        } else {
+            tb_load_window(g, smem + (size_t)((nwin - 1) & 1) * win_bytes, nwin - 1, threadIdx.x, blockDim.x);
+        }
         __syncthreads();
     }
     for (int j = nwin - 1; j >= 0; j--) {
-        if (g.chunk > 0 && j > 0 && threadIdx.x >= 64) tb_load_window(g, smem + (size_t)((j - 1) & 1) * win_bytes, j - 1, threadIdx.x - 64, blockDim.x - 64);
+        if (cor && j > 0) {
+            // the next window's corridor is centred on the column the walk has now, on entering window j
+            if (threadIdx.x == 0) {
+                const int aa = xx + yy;
+                const int bnow = (aa >= 0 && aa < Aout) ? yy - g.boff[aa] : 0;
+                int c = (bnow - g.cw / 2) & ~15;
+                c = c < 0 ? 0 : (c > B - g.cw ? B - g.cw : c);
+                sh_c0[(j - 1) & 1] = c;
+            }
+            __syncthreads();
+            if (threadIdx.x >= 64) tb_load_corridor(g, smem + (size_t)((j - 1) & 1) * win_bytes, j - 1, sh_c0[(j - 1) & 1], threadIdx.x - 64, blockDim.x - 64);
+        } else if (g.chunk > 0 && j > 0 && threadIdx.x >= 64) tb_load_window(g, smem + (size_t)((j - 1) & 1) * win_bytes, j - 1, threadIdx.x - 64, blockDim.x - 64);
         if (threadIdx.x == 0 && !done && !err) {
             const int lo = g.chunk > 0 ? j * g.chunk : 0;
             const char* win = smem + (size_t)(j & 1) * win_bytes;
             const unsigned char* lbp = reinterpret_cast<const unsigned char*>(win);
             const unsigned short* lbw = reinterpret_cast<const unsigned short*>(win);
-            const int* lbo = reinterpret_cast<const int*>(win + ((((size_t)g.chunk * B * (wide ? 2 : 1)) + 15) & ~(size_t)15));
+            const int* lbo = reinterpret_cast<const int*>(win + ((((size_t)g.chunk * (cor ? g.cw : B) * ((wide && !cor) ? 2 : 1)) + 15) & ~(size_t)15));
+            const int c0w = cor ? sh_c0[j & 1] : 0;
             for (;;) {
                 if (xx == 0 && yy == 0) { done = true; break; }
                 const int aa = xx + yy;
@@ -718,7 +763,12 @@ __device__ void sparse_traceback_block(const TbArgs& g, char* smem) {
                 const int bb = yy - (g.chunk > 0 ? lbo[aa - lo] : g.boff[aa]);
                 if (bb < 0 || bb >= B) { err = SVX_ERR_TRACEBACK; break; }
                 int px, py;
-                if (g.chunk > 0) {
+                if (cor) {
+                    const int cc = bb - c0w;
+                    const unsigned char v = (cc >= 0 && cc < g.cw) ? lbp[(size_t)(aa - lo) * g.cw + cc] : g.bpk[(size_t)aa * B + bb];
+                    px = v == 0xFF ? -42 : (v >> 4);
+                    py = v == 0xFF ? -42 : (v & 15);
+                } else if (g.chunk > 0) {
                     const size_t o = (size_t)(aa - lo) * B + bb;
                     if (!wide) {
                         const unsigned char v = lbp[o];
@@ -802,7 +852,7 @@ __global__ __launch_bounds__(256) void k_sparse_traceback(TbArgs g) {
 }
 
 __global__ __launch_bounds__(256) void k_sparse_traceback_batch(const SvxPairDev* __restrict__ pairs, int depth, int B,
-                                                                int chunk) {
+                                                                int chunk, int cw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SvxPairDev& P = pairs[blockIdx.x];
     if (depth > P.L || (depth == P.L && P.L > 0)) return;
@@ -815,6 +865,7 @@ __global__ __launch_bounds__(256) void k_sparse_traceback_batch(const SvxPairDev
     g.Aout = A + 2; g.B = B; g.xs = Lv.n[0]; g.ys = Lv.n[1];
     g.align = Lv.align; g.scores = Lv.scores; g.count = Lv.n_align; g.status = P.status;
     g.chunk = chunk;
+    g.cw = cw;
     sparse_traceback_block(g, smem);
 }
 
@@ -1304,6 +1355,7 @@ int svxl_sparse_traceback(svx_ctx* ctx, const double* csum, const int* xp, const
     g.Aout = a_out; g.B = B; g.xs = xs; g.ys = ys;
     g.align = align; g.scores = scores; g.count = count; g.status = nullptr;
     g.chunk = tb_chunk(B, true);
+    g.cw = 0;
     const size_t smem = g.chunk > 0 ? tb_smem_bytes(g.chunk, B, true) : 0;
     if (smem > 64 * 1024)
         SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_traceback, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1314,12 +1366,17 @@ int svxl_sparse_traceback(svx_ctx* ctx, const double* csum, const int* xp, const
 
 int svxl_sparse_traceback_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int depth, int B, int max_A, int packed) {
     if (n_pairs <= 0) return SVX_OK;
-    const int chunk = tb_chunk(B, !packed);
-    const size_t smem = chunk > 0 ? tb_smem_bytes(chunk, B, !packed) : 0;
+    int chunk = tb_chunk(B, !packed), cw = 0;
+    size_t smem = chunk > 0 ? tb_smem_bytes(chunk, B, !packed) : 0;
+    if (chunk == 0 && packed && B > TB_COR_W && B % 16 == 0) {  // wide band: corridor windows
+        chunk = TB_COR_CHUNK;
+        cw = TB_COR_W;
+        smem = 2 * tb_win_bytes(chunk, cw, false);
+    }
     (void)max_A;
     if (smem > 64 * 1024)
         SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_sparse_traceback_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(k_sparse_traceback_batch, dim3(n_pairs), dim3(256), smem, ctx->stream, pairs, depth, B, chunk);
+    hipLaunchKernelGGL(k_sparse_traceback_batch, dim3(n_pairs), dim3(256), smem, ctx->stream, pairs, depth, B, chunk, cw);
     SVX_LAUNCH_CHECK(ctx, "k_sparse_traceback_batch");
     return SVX_OK;
 }
@@ -1356,6 +1413,7 @@ int svxl_search_path_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, i
         SVX_HIP(ctx, hipFuncSetAttribute((const void*)k_search_path_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(k_search_path_batch, dim3(n_pairs), dim3(256), smem, ctx->stream, pairs, depth, rows);
     SVX_LAUNCH_CHECK(ctx, "k_search_path_batch");
+    if (chunk_tamax <= 0) return SVX_OK;  // (the tile sweep of wide straight bands has no use for band-cost chunks)
     int ints = max_rows + 4;  // path points of the longest pair (= its n + m + 4 bound)
     if (ints > 36 * 1024) ints = 36 * 1024;
     const size_t csmem = (size_t)ints * sizeof(int);

@@ -20,6 +20,7 @@
 // order -- compute the cost planes first (they need no neighbour), then wait for the neighbours' flags.
 // Results go to the reference's node arrays (csum [A+2][B] float64, packed back-pointers), which the existing
 // traceback kernel walks.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -129,16 +130,35 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const SvxPairDev* __restric
     }
 }
 
-// pair_pref[p] = tickets before pair p; zero the ticket counter
-__global__ void k_tile_prefix(const SvxPairDev* __restrict__ pairs, int n_pairs, int* pair_pref, int* ticket) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int run = 0;
-    for (int p = 0; p < n_pairs; p++) {
-        pair_pref[p] = run;
-        run += pairs[p].t_pref[pairs[p].t_nd];
+// Ticket order: tile anti-diagonal s of every pair, then s + 1 of every pair, ...: the pairs of a batch advance
+// together, so that the chip sees (pairs x tiles per diagonal) independent tiles instead of one pair's wavefront.
+// gpref[s * n_pairs + p] = tickets before (s, p); gpref[max_nd * n_pairs] = total.  One workgroup, blocked scan.
+__global__ __launch_bounds__(1024) void k_tile_prefix(const SvxPairDev* __restrict__ pairs, int n_pairs, int max_nd, int* gpref, int* ticket) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const long long n = (long long)max_nd * n_pairs;
+    const long long per = (n + 1023) / 1024;
+    const long long lo = tid * per, hi = (lo + per) < n ? (lo + per) : n;
+    int sum = 0;
+    for (long long e = lo; e < hi; e++) {
+        const int s = (int)(e / n_pairs), p = (int)(e % n_pairs);
+        sum += s < pairs[p].t_nd ? pairs[p].t_cnt[s] : 0;
     }
-    pair_pref[n_pairs] = run;
-    *ticket = 0;
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; i++) { const int v = part[i]; part[i] = run; run += v; }
+        gpref[n] = run;
+        *ticket = 0;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (long long e = lo; e < hi; e++) {
+        const int s = (int)(e / n_pairs), p = (int)(e % n_pairs);
+        gpref[e] = run;
+        run += s < pairs[p].t_nd ? pairs[p].t_cnt[s] : 0;
+    }
 }
 
 template <typename E, int NSLOT, int UPW, int S>
@@ -158,7 +178,8 @@ struct DpMerge {
 
 template <typename E, int NSLOT, int UPW, int S>
 __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __restrict__ pairs, int n_pairs, SvxTypes ty, TilePlan plan,
-                                                           int W, const int* __restrict__ pair_pref, int* ticket) {
+                                                           int W, int max_nd, const int* __restrict__ gpref, int* ticket,
+                                                           unsigned long long* prof) {
     using C = TileCfg<E, NSLOT, UPW, S>;
     using St = typename E::storage;
     constexpr int PW = C::PW;
@@ -166,7 +187,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
     __shared__ __attribute__((aligned(1024))) char st1[C::STAGE];
     __shared__ __attribute__((aligned(1024))) char st2[S >= 3 ? C::STAGE : 16];
     __shared__ __attribute__((aligned(16))) float planes[C::TPP * TL * TL];   // [type][x row][y row] costs of the tile
-    __shared__ __attribute__((aligned(16))) double cs[CS_W * CS_W];           // csum of the tile's nodes, halo first
+    __shared__ __attribute__((aligned(16))) double cs[CS_W * CS_W + 2];       // csum of the tile's nodes and halo; [CS_W^2] = +inf
     __shared__ unsigned char bpt[TL * TL];
     __shared__ float snrm[NSLOT * TL], sinv[NSLOT * TL];
     __shared__ int bo_l[2 * TL + 2 * TT_HALO + 2];
@@ -175,30 +196,45 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int B = 2 * W, T = ty.n, NTt = T + 2, H = plan.halo;
-    const int total = pair_pref[n_pairs];
+    const long long nent = (long long)max_nd * n_pairs;
+    const int total = gpref[nent];
     for (int t = tid; t < NTt; t += TT_THREADS) tpk[t] = (int)ty.x[t] | ((int)ty.y[t] << 8);
     const int lrow = lane & 15, lkg = lane >> 4;
     const int loff = lrow * TT_SLAB + 16 * (lkg ^ swz_t(lrow));
     const double inf = __builtin_inf();
-    int pcur = 0;  // tickets are handed out in pair order: the pair index only moves forward
+    long long ecur = 0;  // tickets grow: the (diagonal, pair) entry of a workgroup's ticket only moves forward
 
+    // (diagnostic build-in: with SVX_TILE_PROF=1 thread 0 sums the 100 MHz ticks of every phase into prof[0..6])
+    unsigned long long t_prev = prof ? __builtin_amdgcn_s_memrealtime() : 0;
+    auto stamp = [&](int slot) {
+        if (prof && tid == 0) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            atomicAdd(prof + slot, now - t_prev);
+            t_prev = now;
+        }
+    };
     for (;;) {
         __syncthreads();  // the previous tile is finished with LDS
+        stamp(6);
         if (tid == 0) sh_ticket = atomicAdd(ticket, 1);
         __syncthreads();
         const int tk = sh_ticket;
         if (tk >= total) break;
-        while (pair_pref[pcur + 1] <= tk) pcur++;
-        const SvxPairDev& P = pairs[pcur];
-        const SvxLevel& Lv = P.lev[0];
-        const int local = tk - pair_pref[pcur];
-        // tile anti-diagonal of the ticket: largest s with t_pref[s] <= local
-        int lo = 0, hi = P.t_nd - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (P.t_pref[mid] <= local) lo = mid; else hi = mid - 1;
+        // (gallop, then bisect: a workgroup's next ticket is usually a few entries ahead)
+        if (gpref[ecur + 1] <= tk) {
+            long long step = 1, lo = ecur + 1, hi = nent - 1;
+            while (lo + step < nent && gpref[lo + step] <= tk) { lo += step; step <<= 1; }
+            if (lo + step < hi) hi = lo + step;
+            while (lo < hi) {
+                const long long mid = (lo + hi + 1) >> 1;
+                if (gpref[mid] <= tk) lo = mid; else hi = mid - 1;
+            }
+            ecur = lo;
         }
-        const int s = lo, I = P.t_lo[s] + (local - P.t_pref[s]), J = s - I;
+        const int s = (int)(ecur / n_pairs);
+        const SvxPairDev& P = pairs[ecur % n_pairs];
+        const SvxLevel& Lv = P.lev[0];
+        const int I = P.t_lo[s] + (tk - gpref[ecur]), J = s - I;
         const int xs = Lv.n[0], ys = Lv.n[1], d = P.d;
         const int rowbytes = d * (int)sizeof(St);
         const int NK = (rowbytes + TT_SLAB - 1) / TT_SLAB;
@@ -206,6 +242,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
         const int A = *Lv.path_len;
         const double pen = *Lv.pen;
 
+        stamp(0);
         // ---- phase 1: cost planes (no neighbour needed)
         constexpr int SPT = (NSLOT * TL + TT_THREADS - 1) / TT_THREADS;
         float r_nrm[SPT], r_inv[SPT];
@@ -339,6 +376,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
                 }
             }
         }
+        stamp(1);
         // ---- phase 2: wait for the neighbours (all three, when they exist, have smaller tickets), then their halo
         if (tid == 0) {
             const int nb[3][2] = {{I - 1, J}, {I, J - 1}, {I - 1, J - 1}};
@@ -357,47 +395,96 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
                 }
                 if (spins >= (1l << 25)) *P.status = SVX_ERR_HIP;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        // csum tile: position (i + H, j + H) <-> node (32 I + i, 32 J + j), i, j in [-H, 32).  Halo nodes come from the
+        stamp(2);
+        // csum tile: position (i + 8, j + 8) <-> node (32 I + i, 32 J + j), i, j in [-H, 32).  Halo nodes come from the
         // neighbours' results; nodes that do not exist or lie outside the band are +inf (a move from them never wins).
-        for (int e = tid; e < CS_W * CS_W; e += TT_THREADS) {
-            const int ii = e / CS_W - TT_HALO, jj = e % CS_W - TT_HALO;
-            double v = inf;
-            if ((ii < 0 || jj < 0) && ii >= -H && jj >= -H) {
-                const int xx = TL * I + ii, yy = TL * J + jj;
-                if (xx >= 0 && yy >= 0 && xx <= xs && yy <= ys) {
-                    const int a = xx + yy, b = yy - bo_l[a - abase];
-                    if (b >= 0 && b < B) v = Lv.csum[(size_t)a * B + b];
+        for (int e = tid; e < CS_W * CS_W + 2; e += TT_THREADS) cs[e] = inf;
+        __syncthreads();
+        {
+            // halo positions: H rows above (H x (32 + H)), then H columns to the left (32 x H); <= 3 per thread, their
+            // loads in flight together
+            const int ntop = H * (TL + H), nhalo = ntop + TL * H;
+            unsigned long long hv[3];
+            int hp[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int h = tid + u * TT_THREADS;
+                hp[u] = -1;
+                hv[u] = 0;
+                if (h < nhalo) {
+                    int ii, jj;
+                    if (h < ntop) { ii = h / (TL + H) - H; jj = h % (TL + H) - H; }
+                    else { ii = (h - ntop) / H; jj = (h - ntop) % H - H; }
+                    const int xx = TL * I + ii, yy = TL * J + jj;
+                    if (xx >= 0 && yy >= 0 && xx <= xs && yy <= ys) {
+                        const int a = xx + yy, b = yy - bo_l[a - abase];
+                        if (b >= 0 && b < B) {
+                            // (a neighbour's value: stored sc1 and drained before its flag, so an sc1 load behind the flag
+                            //  poll sees it without an agent-scope acquire: MI355X_MICROARCH.md, hand-offs with sc1 loads)
+                            hp[u] = (ii + TT_HALO) * CS_W + (jj + TT_HALO);
+                            hv[u] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(Lv.csum) + ((size_t)a * B + b),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
                 }
             }
-            cs[e] = v;
+#pragma unroll
+            for (int u = 0; u < 3; u++)
+                if (hp[u] >= 0) cs[hp[u]] = __longlong_as_double((long long)hv[u]);
         }
         __syncthreads();
+        stamp(3);
         // ---- phase 3: the tile's 63 node anti-diagonals, one wave; half-wave h relaxes the moves t = h, h + 2, ...
+        // A half's moves sit in registers (MH of them, unrolled): per diagonal all their csum / cost reads are issued
+        // together, so a diagonal costs one LDS round trip instead of one per move.
         if (wave == 0) {
+            constexpr int MH = (TT_MAXT + 2 + 1) / 2;
             const int j = lane & 31, half = lane >> 5;
+            int m_off[MH], m_key[MH], m_plb[MH];
+            bool m_ok[MH], m_del[MH];
+#pragma unroll
+            for (int m = 0; m < MH; m++) {
+                const int t = half + 2 * m;
+                const int pk = t < NTt ? tpk[t] : 0;
+                m_ok[m] = t < NTt;
+                m_off[m] = -((pk & 255) * CS_W + (pk >> 8));   // csum position of the predecessor, relative
+                m_key[m] = (t << 16) | pk;
+                m_del[m] = !(t < T);                           // a deletion costs `pen`
+                m_plb[m] = t < T ? t * TL * TL : 0;            // cost plane of the move (any plane for the others: value unused)
+            }
+            // The loop body has no branch and one LDS round trip: every read of a diagonal is issued up front with
+            // addresses that are always valid (lanes outside the tile shadow row 0; moves a half does not have, and
+            // predecessors outside the lattice or the band, read a +inf cell).  Only this wave touches cs / bpt here,
+            // and a wave's LDS operations execute in order, so the writes of one diagonal need no wait before the next.
             for (int dd = 0; dd <= 2 * (TL - 1); dd++) {
                 const int i = dd - j;
                 const bool inside = i >= 0 && i < TL;
-                const int xx = TL * I + i, yy = TL * J + j;
+                const int ic = inside ? i : 0;
+                const int xx = TL * I + ic, yy = TL * J + j;
                 const int a = xx + yy;
-                const int b = inside ? yy - bo_l[a - abase] : -1;
+                const int cpos = (ic + TT_HALO) * CS_W + (j + TT_HALO), ppos = ic * TL + j;
+                const int bo = bo_l[a - abase];
+                double pv[MH];
+                float cv[MH];
+#pragma unroll
+                for (int m = 0; m < MH; m++) {
+                    pv[m] = cs[m_ok[m] ? cpos + m_off[m] : CS_W * CS_W];
+                    cv[m] = planes[m_plb[m] + ppos];
+                }
+                const int b = yy - bo;
                 const bool node = inside && xx <= xs && yy <= ys && b >= 0 && b < B;
                 const bool general = node && xx >= 1 && yy >= 1 && (a - 2) < A;
                 DpMerge best{inf, 0x7fffffff};
-                if (general) {
-                    for (int t = half; t < NTt; t += 2) {
-                        const int xo = tpk[t] & 255, yo = tpk[t] >> 8;
-                        if (xo > xx || yo > yy) continue;
-                        const double prev = cs[(i - xo + TT_HALO) * CS_W + (j - yo + TT_HALO)];
-                        const double c = t < T ? (double)planes[(t * TL + i) * TL + j] : pen;
-                        const double tot = prev + c;
-                        if (tot < best.tot) { best.tot = tot; best.key = (t << 16) | tpk[t]; }
-                    }
+#pragma unroll
+                for (int m = 0; m < MH; m++) {
+                    const double tot = pv[m] + (m_del[m] ? pen : (double)cv[m]);
+                    const bool take = tot < best.tot;
+                    best.tot = take ? tot : best.tot;
+                    best.key = take ? m_key[m] : best.key;
                 }
+                if (!general) { best.tot = inf; best.key = 0x7fffffff; }
                 {   // merge the two halves by (total, move index)
                     const unsigned long long u = __double_as_longlong(best.tot);
                     const unsigned ol = xchg32_u32((unsigned)u, lane), oh = xchg32_u32((unsigned)(u >> 32), lane);
@@ -410,33 +497,38 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
                 if (node && xx == 0) { v = pen * (double)yy; bx = 0; by = 1; }
                 else if (node && yy == 0) { v = pen * (double)xx; bx = 1; by = 0; }
                 if (inside && half == 0) {
-                    cs[(i + TT_HALO) * CS_W + (j + TT_HALO)] = node ? v : inf;
-                    bpt[i * TL + j] = (!node || bx < 0) ? (unsigned char)0xFF : (unsigned char)((bx << 4) | by);
+                    cs[cpos] = node ? v : inf;
+                    bpt[ppos] = (!node || bx < 0) ? (unsigned char)0xFF : (unsigned char)((bx << 4) | by);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                asm volatile("" ::: "memory");   // (keep the next diagonal's reads behind these writes in program order)
             }
         }
         __syncthreads();
-        // ---- phase 4: results into the node arrays, then the flag
-        for (int e = tid; e < TL * TL; e += TT_THREADS) {
-            const int i = e / TL, j2 = e % TL;
-            const int xx = TL * I + i, yy = TL * J + j2;
-            if (xx > xs || yy > ys) continue;
-            const int a = xx + yy, b = yy - bo_l[a - abase];
-            if (b < 0 || b >= B) continue;
-            const size_t o = (size_t)a * B + b;
-            Lv.csum[o] = cs[(i + TT_HALO) * CS_W + (j2 + TT_HALO)];
-            Lv.bpk[o] = bpt[e];
-        }
+        stamp(4);
+        // ---- phase 4: results into the node arrays.  What the neighbours read (the last H rows and columns) goes first,
+        // sc1 and drained, then the flag; the interior follows with plain stores (only the traceback kernel reads it).
+        auto store_nodes = [&](bool edge) {
+            for (int e = tid; e < TL * TL; e += TT_THREADS) {
+                const int i = e / TL, j2 = e % TL;
+                if ((i >= TL - H || j2 >= TL - H) != edge) continue;
+                const int xx = TL * I + i, yy = TL * J + j2;
+                if (xx > xs || yy > ys) continue;
+                const int a = xx + yy, b = yy - bo_l[a - abase];
+                if (b < 0 || b >= B) continue;
+                const size_t o = (size_t)a * B + b;
+                const double v = cs[(i + TT_HALO) * CS_W + (j2 + TT_HALO)];
+                if (edge) __hip_atomic_store(reinterpret_cast<unsigned long long*>(Lv.csum) + o, (unsigned long long)__double_as_longlong(v),
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else Lv.csum[o] = v;
+                Lv.bpk[o] = bpt[e];
+            }
+        };
+        store_nodes(true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(P.t_flag + P.t_pref[s] + (I - P.t_lo[s]), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) __hip_atomic_store(P.t_flag + P.t_pref[s] + (I - P.t_lo[s]), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stamp(5);
+        store_nodes(false);
     }
 }
 
@@ -470,10 +562,10 @@ bool svxl_band_tiles_ok(const SvxTypes& types) {
     return make_tile_plan(types, 10, 8, &plan) || make_tile_plan(types, 16, 12, &plan);
 }
 
-// b_offset_out, tile ranges (which also clear the pairs' tile flags), ticket tables, then the persistent tile sweep.
-// pair_pref [n_pairs + 1] and ticket live in the arena.
-int svxl_band_tiles_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, const SvxTypes& types, int W, int dtype, int* pair_pref,
-                          int* ticket) {
+// b_offset_out, tile ranges (which also clear the pairs' tile flags), ticket table, then the persistent tile sweep.
+// gpref [max_nd * n_pairs + 1] and ticket live in the arena.
+int svxl_band_tiles_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, const SvxTypes& types, int W, int dtype, int max_nd,
+                          int* gpref, int* ticket) {
     if (n_pairs <= 0) return SVX_OK;
     hipStream_t st = ctx->stream;
     TilePlan plan;
@@ -481,7 +573,7 @@ int svxl_band_tiles_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, co
     if (!small && !make_tile_plan(types, 16, 12, &plan))
         return svx_fail(ctx, SVX_ERR_ARG, "wide band: %d alignment types / their overlap layers exceed the tile kernel (16 types, 12 layers, steps <= 8)", types.n);
     hipLaunchKernelGGL(k_tile_ranges, dim3(n_pairs), dim3(256), 0, st, pairs, W, 2 * W);
-    hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(64), 0, st, pairs, n_pairs, pair_pref, ticket);
+    hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, st, pairs, n_pairs, max_nd, gpref, ticket);
     SVX_LAUNCH_CHECK(ctx, "k_tile_ranges");
     int dev = 0, ncu = 256;
     (void)hipGetDevice(&dev);
@@ -489,15 +581,32 @@ int svxl_band_tiles_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, co
     // one persistent workgroup per CU (> 100 KB of LDS each): all of them are resident, so a workgroup that waits for
     // a neighbour's flag always waits for a running workgroup
     dim3 grid((unsigned)ncu);
+    const char* penv = getenv("SVX_TILE_PROF");
+    unsigned long long* prof = nullptr;
+    if (penv && atoi(penv) != 0) {
+        SVX_HIP(ctx, hipMalloc(&prof, 8 * sizeof(unsigned long long)));
+        SVX_HIP(ctx, hipMemsetAsync(prof, 0, 8 * sizeof(unsigned long long), st));
+    }
 #define TILES(E)                                                                                                                   \
     do {                                                                                                                           \
-        if (small) hipLaunchKernelGGL((k_band_tiles<E, 8, 5, 3>), grid, dim3(TT_THREADS), 0, st, pairs, n_pairs, types, plan, W, pair_pref, ticket); \
-        else hipLaunchKernelGGL((k_band_tiles<E, 12, 8, 2>), grid, dim3(TT_THREADS), 0, st, pairs, n_pairs, types, plan, W, pair_pref, ticket); \
+        if (small) hipLaunchKernelGGL((k_band_tiles<E, 8, 5, 3>), grid, dim3(TT_THREADS), 0, st, pairs, n_pairs, types, plan, W, max_nd, gpref, ticket, prof); \
+        else hipLaunchKernelGGL((k_band_tiles<E, 12, 8, 2>), grid, dim3(TT_THREADS), 0, st, pairs, n_pairs, types, plan, W, max_nd, gpref, ticket, prof); \
     } while (0)
     if (dtype == SVX_F32) TILES(ElemF32);
     else if (dtype == SVX_F16) TILES(ElemF16);
     else TILES(ElemBF16);
 #undef TILES
     SVX_LAUNCH_CHECK(ctx, "k_band_tiles");
+    if (prof) {
+        unsigned long long h[8];
+        SVX_HIP(ctx, hipMemcpyAsync(h, prof, sizeof(h), hipMemcpyDeviceToHost, st));
+        SVX_HIP(ctx, hipStreamSynchronize(st));
+        (void)hipFree(prof);
+        static const char* nm[7] = {"ticket+lookup", "costs", "wait", "halo", "cs-init..dp-start", "store+flag", "interior-store+loop"};
+        // (slot 3 = halo fill, slot 4 = the DP sweep; names follow the stamps' positions)
+        fprintf(stderr, "[svx tile sweep, summed over %d workgroups, ms]", ncu);
+        for (int i = 0; i < 7; i++) fprintf(stderr, " p%d(%s)=%.2f", i, nm[i], (double)h[i] * 1e-5);
+        fprintf(stderr, "\n");
+    }
     return SVX_OK;
 }
