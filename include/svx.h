@@ -244,6 +244,30 @@ int64_t svx_knob_count(int n_l, int m_l, int costs_sample_size);
  * ['final_alignments'] and ['alignment_scores'] per pair. */
 int svx_align_batch(svx_ctx *ctx, const svx_align_params *params, const svx_pair *pairs, int n_pairs);
 
+/* Per-level intermediates of the LAST svx_align_batch call on this context -- the entries of the `stack` the reference
+ * returns (dp_utils.py:412-537) -- as device pointers into the context's scratch arena (valid until the next call;
+ * the scalar fields are read back, which synchronises the stream).  Pointers are NULL for what a level does not have
+ * (the coarsest level of a pyramid only has normalisers, penalty and alignments; the tile sweep keeps no cost array). */
+typedef struct svx_level_view {
+    int32_t size0, size1, k0, k1;   /* rows and overlap layers of the two sides at this depth */
+    int32_t n_types, band;          /* alignment types of this depth, cells per diagonal (2 * width_over2) */
+    int32_t path_len, n_align;      /* search path points (= len(b_offset)); alignments of this depth */
+    const float *n0, *n1;           /* [k0][size0], [k1][size1]   stack[d]['n0'], ['n1'] */
+    const double *del_penalty;      /* [1]                        stack[d]['del_penalty'] */
+    const int32_t *searchpath;      /* [path_len][2]              stack[d]['searchpath'] */
+    const float *a_b_costs;         /* [path_len][n_types][band]  stack[d]['a_b_costs'], diagonal-major ([T][A][B] in the reference) */
+    const int32_t *b_offset;        /* [path_len]                 stack[d]['b_offset'] */
+    const double *a_b_csum;         /* [path_len + 2][band]       stack[d]['a_b_csum'] */
+    const uint8_t *a_b_bp;          /* [path_len + 2][band] xp << 4 | yp, 0xFF = -42, or NULL when ... */
+    const int32_t *a_b_xp, *a_b_yp; /* ... the types do not pack into 4 bits (then these are set) */
+    const int32_t *new_b_offset;    /* [path_len + 2]             stack[d]['new_b_offset'] */
+    const int32_t *alignments;      /* [n_align][4] rows (x_start, x_len, y_start, y_len) */
+    const double *alignment_scores; /* [n_align] (refined levels) */
+} svx_level_view;
+int svx_debug_level(svx_ctx *ctx, int pair, int level, svx_level_view *out);
+/* Synchronous device -> host copy behind the context's stream (for reading svx_level_view arrays without a tensor library). */
+int svx_copy_to_host(svx_ctx *ctx, void *dst_host, const void *src_device, int64_t bytes);
+
 /* Device time of the named stage of the last svx_align_batch call, in milliseconds, measured with
  * HIP events on the context's stream when profiling is on (svx_set_profiling); one name per kernel:
  * "pyr0" "pyr1" "pyrN" "pyr_aux" "knob_sort" "knob_scores0" "knob_scoresN" "knob" "dense_costs" "dense_dp" "path"

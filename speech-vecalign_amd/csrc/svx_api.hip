@@ -49,6 +49,7 @@ struct svx_ctx_ext : svx_ctx {
     hipStream_t side;
     hipEvent_t side_fork, side_join;
     bool side_ready;
+    int last_ntypes, last_band;  // of the last svx_align_batch call (svx_debug_level)
 };
 
 static inline svx_ctx_ext* X(svx_ctx* c) { return static_cast<svx_ctx_ext*>(c); }
@@ -97,6 +98,8 @@ int svx_create(int device_id, svx_ctx** out) {
     c->profiling = 0;
     for (int i = 0; i < S_COUNT; i++) { c->ms[i] = -1.0; c->launches[i] = 0; }
     c->n_streams = 1;
+    c->last_ntypes = 0;
+    c->last_band = 0;
     c->aux_ready = false;
     c->side_ready = false;
     *out = c;
@@ -399,6 +402,49 @@ __global__ void k_init_batch(const SvxPairDev* pairs) {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+extern "C" int svx_copy_to_host(svx_ctx* ctx, void* dst_host, const void* src_device, int64_t bytes) {
+    NEED(ctx, ctx && (bytes == 0 || (dst_host && src_device)) && bytes >= 0, "svx_copy_to_host: bad argument");
+    if (bytes == 0) return SVX_OK;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    SVX_HIP(ctx, hipMemcpyAsync(dst_host, src_device, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SVX_OK;
+}
+
+extern "C" int svx_debug_level(svx_ctx* ctx, int pair, int level, svx_level_view* out) {
+    NEED(ctx, ctx && out, "svx_debug_level: null argument");
+    svx_ctx_ext* cx = X(ctx);
+    NEED(ctx, pair >= 0 && pair < (int)cx->host.size(), "svx_debug_level: pair %d of the last batch (%d pairs)", pair, (int)cx->host.size());
+    const SvxPairDev& P = cx->host[pair];
+    NEED(ctx, level >= 0 && level <= P.L, "svx_debug_level: level %d (the pair has %d)", level, P.L + 1);
+    const SvxLevel& Lv = P.lev[level];
+    memset(out, 0, sizeof(*out));
+    out->size0 = Lv.n[0]; out->size1 = Lv.n[1];
+    out->k0 = P.K[0]; out->k1 = P.K[1];
+    out->n_types = level == 0 ? cx->last_ntypes : 1;
+    out->band = cx->last_band;
+    out->n0 = Lv.nrm[0]; out->n1 = Lv.nrm[1];
+    out->del_penalty = Lv.pen;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (Lv.n_align) SVX_HIP(ctx, hipMemcpy(&out->n_align, Lv.n_align, sizeof(int), hipMemcpyDeviceToHost));
+    out->alignments = Lv.align;
+    const bool refined = (level < P.L) || (P.L == 0);
+    if (refined) {
+        SVX_HIP(ctx, hipMemcpy(&out->path_len, Lv.path_len, sizeof(int), hipMemcpyDeviceToHost));
+        out->searchpath = Lv.path;
+        out->a_b_costs = Lv.costs;
+        out->b_offset = Lv.boff;
+        out->a_b_csum = Lv.csum;
+        out->a_b_bp = Lv.bpk;
+        out->a_b_xp = Lv.xp;
+        out->a_b_yp = Lv.yp;
+        out->new_b_offset = Lv.boff_out;
+        out->alignment_scores = Lv.scores;
+    }
+    return SVX_OK;
+}
+
 extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const svx_pair* pairs, int n_pairs) {
     NEED(ctx, ctx && prm && (pairs || n_pairs == 0), "svx_align_batch: null argument");
     if (n_pairs <= 0) return SVX_OK;
@@ -423,6 +469,8 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
     const bool packable = mx <= 15 && my <= 15;  // back-pointers fit 4 bits each
     NEED(ctx, prm->search_mode == SVX_SEARCH_COARSE_TO_FINE || prm->search_mode == SVX_SEARCH_STRAIGHT, "svx_align_batch: unknown search_mode %d", prm->search_mode);
     const bool straight = prm->search_mode == SVX_SEARCH_STRAIGHT;
+    cx->last_ntypes = tfinal.n;
+    cx->last_band = B;
     // straight search with a band wider than the one-workgroup DP kernel takes: wavefront of tiles (svx_tiles.hip)
     const bool tiles = straight && B > 64;
     if (tiles) {

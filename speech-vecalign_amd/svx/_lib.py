@@ -43,6 +43,16 @@ class AlignParams(ctypes.Structure):
     ]
 
 
+class LevelView(ctypes.Structure):
+    _fields_ = [
+        ("size0", ctypes.c_int32), ("size1", ctypes.c_int32), ("k0", ctypes.c_int32), ("k1", ctypes.c_int32),
+        ("n_types", ctypes.c_int32), ("band", ctypes.c_int32), ("path_len", ctypes.c_int32), ("n_align", ctypes.c_int32),
+        ("n0", c_vp), ("n1", c_vp), ("del_penalty", c_vp), ("searchpath", c_vp), ("a_b_costs", c_vp), ("b_offset", c_vp),
+        ("a_b_csum", c_vp), ("a_b_bp", c_vp), ("a_b_xp", c_vp), ("a_b_yp", c_vp), ("new_b_offset", c_vp),
+        ("alignments", c_vp), ("alignment_scores", c_vp),
+    ]
+
+
 class Pair(ctypes.Structure):
     _fields_ = [
         ("vecs0", c_vp), ("vecs1", c_vp),
@@ -90,6 +100,8 @@ _SIGS = {
     "svx_num_levels": (c_int, [c_int, c_int, c_int]),
     "svx_knob_count": (c_i64, [c_int, c_int, c_int]),
     "svx_align_batch": (c_int, [c_vp, ctypes.POINTER(AlignParams), ctypes.POINTER(Pair), c_int]),
+    "svx_debug_level": (c_int, [c_vp, c_int, c_int, ctypes.POINTER(LevelView)]),
+    "svx_copy_to_host": (c_int, [c_vp, c_vp, c_vp, c_i64]),
     "svx_set_profiling": (c_int, [c_vp, c_int]),
     "svx_set_streams": (c_int, [c_vp, c_int]),
     "svx_stage_ms": (c_f64, [c_vp, ctypes.c_char_p]),

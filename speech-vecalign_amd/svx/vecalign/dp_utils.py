@@ -296,6 +296,48 @@ class PreparedBatch:
             raise Exception(_lib.DEVICE_ERRORS.get(code, "device failure %d" % code))
         return info, align, scores, pens, self.offs
 
+    def level_stack(self, i, depth):
+        """The reference's stack[depth] entries (dp_utils.py:412-537) of pair `i` of the last run(), copied from
+        the device (svx_debug_level): n0, n1, del_penalty, and for refined levels searchpath, a_b_costs [T][A][B],
+        b_offset, a_b_csum, a_b_xp, a_b_yp, new_b_offset, alignments, alignment_scores."""
+        ctx = self.ctx
+        t = ctx.torch
+        v = _lib.LevelView()
+        ctx.check(ctx.lib.svx_debug_level(ctx.h, int(i), int(depth), ctypes.byref(v)))
+
+        npdt = {t.float32: np.float32, t.float64: np.float64, t.int32: np.int32, t.uint8: np.uint8}
+
+        def arr(ptr, shape, dt):
+            if not ptr:
+                return None
+            out = np.empty(shape, dtype=npdt[dt])
+            if out.size:
+                ctx.check(ctx.lib.svx_copy_to_host(ctx.h, ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(ptr), out.nbytes))
+            return out
+        d = {'size0': v.size0, 'size1': v.size1,
+             'alignment_types': list(self.types) if depth == 0 else [(1, 1)],
+             'n0': arr(v.n0, (v.k0, v.size0), t.float32), 'n1': arr(v.n1, (v.k1, v.size1), t.float32),
+             'del_penalty': float(arr(v.del_penalty, (1,), t.float64)[0])}
+        if v.alignments and v.n_align >= 0:
+            d['alignments'] = rows_to_alignments(arr(v.alignments, (v.n_align, 4), t.int32))
+        if v.searchpath:
+            A, B, T = v.path_len, v.band, v.n_types
+            d['searchpath'] = [tuple(p) for p in arr(v.searchpath, (A, 2), t.int32).tolist()]
+            d['b_offset'] = arr(v.b_offset, (A,), t.int32)
+            if v.a_b_costs:
+                d['a_b_costs'] = np.ascontiguousarray(arr(v.a_b_costs, (A, T, B), t.float32).transpose(1, 0, 2))
+            d['a_b_csum'] = arr(v.a_b_csum, (A + 2, B), t.float64)
+            if v.a_b_bp:
+                bp = arr(v.a_b_bp, (A + 2, B), t.uint8).astype(np.int32)
+                d['a_b_xp'] = np.where(bp == 255, -42, bp >> 4).astype(np.int32)
+                d['a_b_yp'] = np.where(bp == 255, -42, bp & 15).astype(np.int32)
+            else:
+                d['a_b_xp'], d['a_b_yp'] = arr(v.a_b_xp, (A + 2, B), t.int32), arr(v.a_b_yp, (A + 2, B), t.int32)
+            d['new_b_offset'] = arr(v.new_b_offset, (A + 2,), t.int32)
+            if v.alignment_scores and v.n_align >= 0:
+                d['alignment_scores'] = arr(v.alignment_scores, (v.n_align,), t.float64)
+        return d
+
     def results(self):
         """-> list of (alignments, scores, del_penalties) per pair; raises on a device-side failure."""
         info, align, scores, pens, offs = self.raw_results()
@@ -318,17 +360,23 @@ def align_batch(pairs, final_alignment_types, del_percentile_frac, width_over2, 
 
 
 def vecalign(vecs0, vecs1, final_alignment_types, del_percentile_frac, width_over2, max_size_full_dp,
-             costs_sample_size, num_samps_for_norm, norms0=None, norms1=None, normalize_inputs_inplace=False):
+             costs_sample_size, num_samps_for_norm, norms0=None, norms1=None, normalize_inputs_inplace=False,
+             full_stack=False):
     """dp_utils.py:381-537.  Returns {0: {'final_alignments', 'alignment_scores', 'del_penalty',
-    'size0', 'size1', 'alignment_types'}, d: {'del_penalty', 'size0', 'size1'} ...}."""
-    res = align_batch([(vecs0, vecs1)], final_alignment_types, del_percentile_frac, width_over2, max_size_full_dp,
-                      costs_sample_size, num_samps_for_norm, norms=[(norms0, norms1)])
-    alignments, scores, pens = res[0]
+    'size0', 'size1', 'alignment_types'}, d: {'del_penalty', 'size0', 'size1'} ...}; with full_stack=True every
+    depth also carries the intermediates the reference keeps (n0, n1, searchpath, a_b_costs, b_offset, a_b_csum,
+    a_b_xp, a_b_yp, new_b_offset, alignments: PreparedBatch.level_stack), copied back from the device."""
+    pb = PreparedBatch([(vecs0, vecs1)], final_alignment_types, del_percentile_frac, width_over2, max_size_full_dp,
+                       costs_sample_size, num_samps_for_norm, norms=[(norms0, norms1)])
+    pb.run()
+    alignments, scores, pens = pb.results()[0]
     sizes = level_sizes(vecs0.shape[1], vecs1.shape[1], max_size_full_dp)
     stack = {}
     for depth, (s0, s1) in enumerate(sizes):
         stack[depth] = {'size0': s0, 'size1': s1, 'del_penalty': float(pens[depth]),
                         'alignment_types': list(final_alignment_types) if depth == 0 else [(1, 1)]}
+        if full_stack:
+            stack[depth].update(pb.level_stack(0, depth))
     stack[0]['final_alignments'] = alignments
     stack[0]['alignment_scores'] = scores
     if normalize_inputs_inplace:

@@ -138,7 +138,7 @@ def align(src: str, tgt: str, src_embed: List[str], src_stopes: bool, tgt_stopes
     stack = vecalign(vecs0=src_vectors, vecs1=tgt_vectors, final_alignment_types=types,
                      del_percentile_frac=del_percentile_frac, width_over2=width_over2,
                      max_size_full_dp=max_size_full_dp, costs_sample_size=costs_sample_size,
-                     num_samps_for_norm=num_samps_for_norm)
+                     num_samps_for_norm=num_samps_for_norm, full_stack=bool(debug_save_stack))
     if print_results:
         fp = open(save_aligned_text_to_file, mode="w") if save_aligned_text_to_file else sys.stdout
         print_alignments(stack[0]['final_alignments'], scores=stack[0]['alignment_scores'],

@@ -38,7 +38,10 @@ def test_vecalign_vs_reference_golden(name):
     v0, v1, types, W, kw = pipeline_inputs(c)
     np.random.seed(c["rng_seed"])
     stack = dp_utils.vecalign(to_dev(v0, kw["dtype"]), to_dev(v1, kw["dtype"]), types, c.get("frac", 0.2), W,
-                              c.get("max_full", 300), c.get("sample", 20000), c.get("nsamp", 100))
+                              c.get("max_full", 300), c.get("sample", 20000), c.get("nsamp", 100), full_stack=True)
+    # intermediates of the fused kernels (svx_debug_level) against what the reference kept in its stack
+    assert np.abs(stack[0]['n0'] - gold[name + "/n0_l0"]).max() < 2e-6
+    assert np.array(stack[0]['searchpath'], np.int64)[:, 1].sum() == gold[name + "/searchpath_sum"][0]
     pens = np.array([stack[d]['del_penalty'] for d in sorted(stack)])
     assert len(pens) == len(gold[name + "/del_pen"])
     assert np.abs(pens - gold[name + "/del_pen"]).max() < 5e-5
@@ -47,6 +50,33 @@ def test_vecalign_vs_reference_golden(name):
     keep = (got[:, 1] > 0) & (got[:, 3] > 0)  # a deletion's start index is not defined by the reference (empty list)
     assert np.array_equal(got[keep], gold[name + "/align"][keep])
     assert np.abs(stack[0]['alignment_scores'] - gold[name + "/scores"]).max() < SCORE_TOL
+
+
+def test_full_stack_vs_oracle(orc):
+    """Every per-level intermediate the reference keeps (dp_utils.py:412-537), read back from the fused pipeline
+    (svx_debug_level) and compared with the oracle's stack: integer arrays exact, costs 4e-6, float64 sums 1e-4."""
+    from svx.vecalign import dp_utils
+    v0, v1 = make_pair(1101, 1003, 4, 64, 4)
+    types = alignment_types(5)
+    np.random.seed(5)
+    ref = orc.vecalign(v0.copy(), v1.copy(), types, 0.2, 7, 300, 20000, 100)
+    np.random.seed(5)
+    got = dp_utils.vecalign(v0, v1, types, 0.2, 7, 300, 20000, 100, full_stack=True)
+    assert len(got) == len(ref) == 3
+    for d in range(3):
+        assert np.abs(got[d]['n0'] - ref[d]['n0']).max() < 4e-6 and np.abs(got[d]['n1'] - ref[d]['n1']).max() < 4e-6
+        assert abs(got[d]['del_penalty'] - ref[d]['del_penalty']) < 5e-5
+        if d < 2:
+            assert got[d]['searchpath'] == [tuple(p) for p in ref[d]['searchpath']]
+            assert np.array_equal(got[d]['b_offset'], ref[d]['b_offset']) and np.array_equal(got[d]['new_b_offset'], ref[d]['new_b_offset'])
+            a, b = got[d]['a_b_costs'], ref[d]['a_b_costs']
+            assert a.shape == b.shape and np.array_equal(np.isinf(a), np.isinf(b))
+            assert np.abs(a[np.isfinite(a)] - b[np.isfinite(b)]).max() < 4e-6
+            assert np.array_equal(got[d]['a_b_xp'], ref[d]['a_b_xp']) and np.array_equal(got[d]['a_b_yp'], ref[d]['a_b_yp'])
+            fin = np.isfinite(ref[d]['a_b_csum'])
+            assert np.array_equal(np.isfinite(got[d]['a_b_csum']), fin)
+            assert np.abs(got[d]['a_b_csum'][fin] - ref[d]['a_b_csum'][fin]).max() < 1e-4 * (1 + ref[d]['a_b_csum'][fin].max())
+        assert got[d]['alignments'] == ref[d]['final_alignments' if d == 0 else 'alignments']
 
 
 def test_benchmark_size_vs_oracle(orc):
@@ -364,3 +394,23 @@ def test_context_follows_current_device():
         assert len(pb.results()[0][0]) > 0
     finally:
         torch.cuda.set_device(cur)
+
+
+@pytest.mark.parametrize("m2o", [8, 50])
+def test_many_to_one_vs_oracle(orc, m2o):
+    """--many_to_one M (vecalign.py:165-171: types (1,1) ... (M,1), M overlap layers on the source side, one on the
+    target side; the CLI default is 50): the band-cost kernel stages the layers a pass of types needs, so the number
+    of layers is not limited by LDS.  M = 50 also exercises unpacked (int32) back-pointers: steps above 15."""
+    from svx.vecalign import dp_utils
+    from svx.vecalign.vecalign import resolve_search_params
+    types, sk, tk, W = resolve_search_params(10, m2o, 5)
+    assert (sk, tk) == (m2o, 1) and len(types) == m2o
+    v0, v1 = make_pair(420, 130, m2o, 64, 77)
+    v1 = np.ascontiguousarray(v1[:1])
+    np.random.seed(13)
+    ref = orc.vecalign(v0.copy(), v1.copy(), types, 0.2, W, 300, 20000, 100)
+    np.random.seed(13)
+    got = dp_utils.vecalign(v0, v1, types, 0.2, W, 300, 20000, 100)
+    assert got[0]['final_alignments'] == ref[0]['final_alignments']
+    assert np.abs(got[0]['alignment_scores'] - ref[0]['alignment_scores']).max() < SCORE_TOL
+    assert max(len(x) for x, _ in got[0]['final_alignments']) > 1
