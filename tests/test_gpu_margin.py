@@ -181,3 +181,23 @@ def test_cli_end_to_end(orc, tmp_path):
             assert (src, tgt) == (f"[{i}]", f"[{i}, {i + 1}]")
             got.append(float(sc))
     assert np.abs(np.array(got, np.float32) - want).max() < 1e-5   # (index rows went through an fp32 file)
+
+
+def test_global_margin_over_rccl():
+    """BASELINE configs[4]'s exchange on real devices: one process per GPU, the ranks' unit rows all-gathered over RCCL
+    (svx.postprocess.flat_index.all_gather_rows), every rank scoring its own shard against the union.  Needs two
+    visible GPUs (the driver's one-GPU box skips it; gloo covers the logic on CPU in tests/test_margin_cpu.py)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs")
+    world = min(n, 4)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                          "--master-port", "29671", os.path.join(os.path.dirname(__file__), "rccl_margin_worker.py")],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "RCCL_MARGIN max|diff|" in out.stdout
