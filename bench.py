@@ -274,7 +274,7 @@ def e2e_files(args, dev, K, N, M, d):
         out_ok = len(os.listdir(os.path.join(root, "out1", "en-de"))) == args.e2e_files
         return {"value": args.e2e_files / best, "unit": "doc-pairs/s", "pairs": args.e2e_files, "seconds_per_pass": times[1:],
                 "first_pass_seconds": times[0], "file_GBps": nbytes / best / 1e9, "outputs_written": bool(out_ok),
-                "generation_seconds": gen_s, "io_threads": min(16, os.cpu_count() or 4),
+                "generation_seconds": gen_s, "io_threads": min(32, os.cpu_count() or 4),
                 "what": "svx.seg_align.align on %d synthetic %dx%d file sets (page cache warm after the first pass): "
                         "files -> alignment files" % (args.e2e_files, N, M)}
     finally:
@@ -408,7 +408,7 @@ def main():
     ap.add_argument("--e2e_pairs", type=int, default=128, help="pool of pairs in pinned host memory for the end-to-end leg; 0 = skip")
     ap.add_argument("--e2e_batch", type=int, default=32)
     ap.add_argument("--e2e_steps", type=int, default=2)
-    ap.add_argument("--e2e_files", type=int, default=32, help="document pairs written to disk for the files leg; 0 = skip")
+    ap.add_argument("--e2e_files", type=int, default=64, help="document pairs written to disk for the files leg; 0 = skip")
     ap.add_argument("--no_profile", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="internal streams a batch is split over (svx_set_streams)")
     args = ap.parse_args()

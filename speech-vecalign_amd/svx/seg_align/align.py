@@ -52,7 +52,7 @@ def parse_args(argv=None):
                    help="if provided, then some segments will be ignored when loading embeddings.")
     # additive
     p.add_argument("--batch_size", type=int, default=32, help="document pairs per device pass")
-    p.add_argument("--io_threads", type=int, default=None, help="host threads that parse / read ahead of the GPU (default: the CPU count, at most 16)")
+    p.add_argument("--io_threads", type=int, default=None, help="host threads that parse / read ahead of the GPU (default: the CPU count, at most 32)")
     p.add_argument("--seed", type=int, default=None, help="derive one sampling stream per pair from (seed, pair index)")
     p.add_argument("--skip_existing", action="store_true", default=False, help="do not recompute existing outputs")
     p.add_argument("--rank", type=int, default=int(os.environ.get("RANK", 0)))
@@ -166,7 +166,7 @@ def align_pairs(pairs: List[VecalignData], args, batch_size: int, io_threads: Op
         return
     ctx = _lib.context()
     dev = ctx.tdev
-    nthr = io_threads or max(2, min(16, (os.cpu_count() or 4)))
+    nthr = io_threads or max(2, min(32, (os.cpu_count() or 4)))
     io_pool, out_pool = ThreadPool(nthr), ThreadPool(max(2, nthr // 2))
     copy_stream = torch.cuda.Stream(device=dev)
     compute = torch.cuda.current_stream(dev)
