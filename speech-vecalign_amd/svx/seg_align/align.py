@@ -51,6 +51,10 @@ def parse_args(argv=None):
     p.add_argument("--ign_indices_dir", type=str, default=None,
                    help="if provided, then some segments will be ignored when loading embeddings.")
     # additive
+    p.add_argument("--mode", choices=["ref", "band", "dense"], default="ref",
+                   help="search region: ref = the reference's coarse-to-fine recursion (default); band = Sakoe-Chiba band of "
+                        "--band cells around the straight diagonal; dense = every cell of the lattice (include/svx.h: SVX_SEARCH_STRAIGHT)")
+    p.add_argument("--band", type=int, default=2048, help="--mode band: cells per diagonal (2 * width_over2)")
     p.add_argument("--batch_size", type=int, default=32, help="document pairs per device pass")
     p.add_argument("--io_threads", type=int, default=None, help="host threads that parse / read ahead of the GPU (default: the CPU count, at most 32)")
     p.add_argument("--seed", type=int, default=None, help="derive one sampling stream per pair from (seed, pair index)")
@@ -213,8 +217,15 @@ def align_pairs(pairs: List[VecalignData], args, batch_size: int, io_threads: Op
                 sv, tv = sv.float(), tv.float()
             docs.append((sv, tv))
         rngs = None if args.seed is None else [pair_rng(args.seed, p.index) for p in chunk]
-        pb = PreparedBatch(docs, types, args.del_percentile_frac, width_over2, args.max_size_full_dp,
-                           args.costs_sample_size, args.num_samps_for_norm, rngs=rngs)
+        mode = getattr(args, "mode", "ref")
+        if mode == "ref":
+            w2, search = width_over2, "coarse_to_fine"
+        elif mode == "band":
+            w2, search = max(3, (args.band + 1) // 2), "straight"
+        else:  # dense: the band covers the lattice (width_over2 > max(N, M))
+            w2, search = max(max(int(sv.shape[1]), int(tv.shape[1])) for sv, tv in docs) + 1, "straight"
+        pb = PreparedBatch(docs, types, args.del_percentile_frac, w2, args.max_size_full_dp,
+                           args.costs_sample_size, args.num_samps_for_norm, rngs=rngs, search=search)
         pb.run()
         ev = pb.fetch_async()
         job = (chunk, pb, ev, (prepared, dev_in))

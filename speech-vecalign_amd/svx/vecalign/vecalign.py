@@ -55,6 +55,11 @@ def parse_args(argv=None):
     p.add_argument("-v", "--verbose", dest="verbose", action="store_true", help='console logging at DEBUG')
     p.add_argument('--debug_save_stack', type=str, default=None, help='Write the result stack to a pickle file')
     p.add_argument("--print_results", default=False, action="store_true", help="whether to print results at all.")
+    # additive: search region (the reference always runs its coarse-to-fine recursion)
+    p.add_argument("--mode", choices=["ref", "band", "dense"], default="ref",
+                   help="ref = coarse-to-fine (default); band = Sakoe-Chiba band of --band cells around the straight diagonal; "
+                        "dense = every cell of the lattice")
+    p.add_argument("--band", type=int, default=2048, help="--mode band: cells per diagonal (2 * width_over2)")
     return p.parse_args(argv)
 
 
@@ -124,7 +129,7 @@ def align(src: str, tgt: str, src_embed: List[str], src_stopes: bool, tgt_stopes
           print_aligned_text: bool, src_fp16: bool = False, tgt_fp16: bool = False,
           src_ignore_indices: Optional[Union[str, Path]] = None, tgt_ignore_indices: Optional[Union[str, Path]] = None,
           verbose: bool = False, debug_save_stack: Optional[str] = None, gold_alignment: Optional[str] = None,
-          print_results: bool = False, save_aligned_text_to_file: Optional[str] = None):
+          print_results: bool = False, save_aligned_text_to_file: Optional[str] = None, mode: str = "ref", band: int = 2048):
     """Align one pair of documents (vecalign.py:198-293); returns the result stack."""
     if verbose:
         logger.setLevel(logging.DEBUG)
@@ -135,10 +140,17 @@ def align(src: str, tgt: str, src_embed: List[str], src_stopes: bool, tgt_stopes
     if src_vectors.dtype != tgt_vectors.dtype:
         src_vectors, tgt_vectors = src_vectors.float(), tgt_vectors.float()
     logger.info(f'Aligning src={src} to tgt={tgt}')
-    stack = vecalign(vecs0=src_vectors, vecs1=tgt_vectors, final_alignment_types=types,
-                     del_percentile_frac=del_percentile_frac, width_over2=width_over2,
-                     max_size_full_dp=max_size_full_dp, costs_sample_size=costs_sample_size,
-                     num_samps_for_norm=num_samps_for_norm, full_stack=bool(debug_save_stack))
+    if mode == "ref":
+        stack = vecalign(vecs0=src_vectors, vecs1=tgt_vectors, final_alignment_types=types,
+                         del_percentile_frac=del_percentile_frac, width_over2=width_over2,
+                         max_size_full_dp=max_size_full_dp, costs_sample_size=costs_sample_size,
+                         num_samps_for_norm=num_samps_for_norm, full_stack=bool(debug_save_stack))
+    else:
+        from .dp_utils import align_band
+        w2 = max(3, (band + 1) // 2) if mode == "band" else max(int(src_vectors.shape[1]), int(tgt_vectors.shape[1])) + 1
+        al, sc = align_band(src_vectors, tgt_vectors, types, del_percentile_frac, w2, costs_sample_size, num_samps_for_norm)
+        stack = {0: {'final_alignments': al, 'alignment_scores': sc, 'size0': int(src_vectors.shape[1]), 'size1': int(tgt_vectors.shape[1]),
+                     'alignment_types': list(types)}}
     if print_results:
         fp = open(save_aligned_text_to_file, mode="w") if save_aligned_text_to_file else sys.stdout
         print_alignments(stack[0]['final_alignments'], scores=stack[0]['alignment_scores'],

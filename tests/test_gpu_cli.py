@@ -74,3 +74,16 @@ def test_seeded_runs_are_batch_invariant(tmp_path):
     stamp = os.path.getmtime(os.path.join(str(tmp_path / "out1"), "en-de", "doc0_en-doc0_de.txt"))
     run_cli(root, str(tmp_path / "out1"), ["--fp16_embed", "--seed", "11", "--skip_existing"])
     assert os.path.getmtime(os.path.join(str(tmp_path / "out1"), "en-de", "doc0_en-doc0_de.txt")) == stamp
+
+
+def test_cli_band_and_dense_modes(tmp_path):
+    """--mode band / dense (additive flags): on the trimmed example the band around the straight diagonal and the whole
+    lattice both contain the optimum the coarse-to-fine search finds, so all three modes print the same spans."""
+    root = str(tmp_path / "data")
+    build_tree(root)
+    outs = {}
+    for mode, extra in (("ref", []), ("band", ["--mode", "band", "--band", "80"]), ("dense", ["--mode", "dense"])):
+        out = str(tmp_path / ("out_" + mode))
+        run_cli(root, out, ["--fp16_embed", "--seed", "3"] + extra)
+        outs[mode] = [(a, b) for a, b, _ in parse(os.path.join(out, "en-de", "doc0_en-doc0_de.txt"))]
+    assert outs["ref"] == outs["dense"] == outs["band"]

@@ -414,3 +414,17 @@ def test_many_to_one_vs_oracle(orc, m2o):
     assert got[0]['final_alignments'] == ref[0]['final_alignments']
     assert np.abs(got[0]['alignment_scores'] - ref[0]['alignment_scores']).max() < SCORE_TOL
     assert max(len(x) for x, _ in got[0]['final_alignments']) > 1
+
+
+def test_straight_narrow_band_vs_oracle(orc):
+    """SVX_SEARCH_STRAIGHT with a band of <= 64 cells takes the band-cost / fast-DP kernels of the coarse-to-fine path
+    (no tile sweep): against the oracle on the same straight path."""
+    from svx.vecalign import dp_utils
+    N, M, K, W = 800, 760, 4, 20
+    v0, v1 = make_pair(N, M, K, 64, 321, deletions=12)
+    types = alignment_types(5)
+    al_o, sc_o = _straight_oracle(orc, v0, v1, types, W, 44)
+    np.random.seed(44)
+    al_g, sc_g = dp_utils.align_band(v0, v1, types, 0.2, W, 20000, 100)
+    assert al_g == al_o
+    assert np.abs(sc_g - sc_o).max() < SCORE_TOL
