@@ -186,6 +186,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
     __shared__ __attribute__((aligned(1024))) char st0[C::STAGE];
     __shared__ __attribute__((aligned(1024))) char st1[C::STAGE];
     __shared__ __attribute__((aligned(1024))) char st2[S >= 3 ? C::STAGE : 16];
+    __shared__ __attribute__((aligned(1024))) char st3[S >= 4 ? C::STAGE : 16];
+    __shared__ __attribute__((aligned(1024))) char st4[S >= 5 ? C::STAGE : 16];
     __shared__ __attribute__((aligned(16))) float planes[C::TPP * TL * TL];   // [type][x row][y row] costs of the tile
     __shared__ __attribute__((aligned(16))) double cs[CS_W * CS_W + 2];       // csum of the tile's nodes and halo; [CS_W^2] = +inf
     __shared__ unsigned char bpt[TL * TL];
@@ -317,14 +319,17 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
                     mma_t16<E>(acc[u2][1], fa[u2], fb[u2][1]);
                 }
         };
-        char* stages[3] = {st0, st1, st2};
+        char* stages[5] = {st0, st1, st2, st3, st4};
+        static_assert(S >= 2 && S <= 5 && 3 * PW <= 63, "ring depth / vmcnt range");
 #pragma unroll
         for (int k = 0; k < S - 1; k++)
             if (k < NK) issue(k, stages[k]);
         auto step = [&](int k, const char* rd, char* wr) {
             if (k < NK) {
-                const int younger = (NK - 1 - k) < (S - 2) ? (NK - 1 - k) : (S - 2);
-                if (younger >= 1) wait_vm_t<PW>();
+                const int younger = (NK - 1 - k) < (S - 2) ? (NK - 1 - k) : (S - 2);  // slabs issued after slab k
+                if (younger >= 3) wait_vm_t<3 * PW>();
+                else if (younger == 2) wait_vm_t<2 * PW>();
+                else if (younger == 1) wait_vm_t<PW>();
                 else wait_vm_t<0>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -336,10 +341,21 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
             if (S == 2) {
                 step(k0, st0, st1);
                 step(k0 + 1, st1, st0);
-            } else {
+            } else if (S == 3) {
                 step(k0, st0, st2);
                 step(k0 + 1, st1, st0);
                 step(k0 + 2, st2, st1);
+            } else if (S == 4) {
+                step(k0, st0, st3);
+                step(k0 + 1, st1, st0);
+                step(k0 + 2, st2, st1);
+                step(k0 + 3, st3, st2);
+            } else {
+                step(k0, st0, st4);
+                step(k0 + 1, st1, st0);
+                step(k0 + 2, st2, st1);
+                step(k0 + 3, st3, st2);
+                step(k0 + 4, st4, st3);
             }
         }
 #pragma unroll
@@ -436,17 +452,19 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
         }
         __syncthreads();
         stamp(3);
-        // ---- phase 3: the tile's 63 node anti-diagonals, one wave; half-wave h relaxes the moves t = h, h + 2, ...
-        // A half's moves sit in registers (MH of them, unrolled): per diagonal all their csum / cost reads are issued
-        // together, so a diagonal costs one LDS round trip instead of one per move.
-        if (wave == 0) {
-            constexpr int MH = (TT_MAXT + 2 + 1) / 2;
-            const int j = lane & 31, half = lane >> 5;
-            int m_off[MH], m_key[MH], m_plb[MH];
-            bool m_ok[MH], m_del[MH];
+        // ---- phase 3: the tile's 63 node anti-diagonals, all four waves: thread = (node j = tid >> 3, move slot = tid & 7).
+        // A slot relaxes the moves t = slot, slot + 8, ... (kept in registers, unrolled) with every csum / cost read of the
+        // diagonal issued up front and no branch; the eight slots of a node sit in eight adjacent lanes and merge by
+        // (total, move index) with three DPP exchanges, so the reference's "first strictly smaller candidate" order holds.
+        // Predecessors outside the lattice or the band, and the moves a slot does not have, read a +inf cell.
+        {
+            constexpr int MS = (TT_MAXT + 2 + 7) / 8;  // moves per slot
+            const int j = tid >> 3, slot = tid & 7;
+            int m_off[MS], m_key[MS], m_plb[MS];
+            bool m_ok[MS], m_del[MS];
 #pragma unroll
-            for (int m = 0; m < MH; m++) {
-                const int t = half + 2 * m;
+            for (int m = 0; m < MS; m++) {
+                const int t = slot + 8 * m;
                 const int pk = t < NTt ? tpk[t] : 0;
                 m_ok[m] = t < NTt;
                 m_off[m] = -((pk & 255) * CS_W + (pk >> 8));   // csum position of the predecessor, relative
@@ -454,10 +472,6 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
                 m_del[m] = !(t < T);                           // a deletion costs `pen`
                 m_plb[m] = t < T ? t * TL * TL : 0;            // cost plane of the move (any plane for the others: value unused)
             }
-            // The loop body has no branch and one LDS round trip: every read of a diagonal is issued up front with
-            // addresses that are always valid (lanes outside the tile shadow row 0; moves a half does not have, and
-            // predecessors outside the lattice or the band, read a +inf cell).  Only this wave touches cs / bpt here,
-            // and a wave's LDS operations execute in order, so the writes of one diagonal need no wait before the next.
             for (int dd = 0; dd <= 2 * (TL - 1); dd++) {
                 const int i = dd - j;
                 const bool inside = i >= 0 && i < TL;
@@ -466,10 +480,10 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
                 const int a = xx + yy;
                 const int cpos = (ic + TT_HALO) * CS_W + (j + TT_HALO), ppos = ic * TL + j;
                 const int bo = bo_l[a - abase];
-                double pv[MH];
-                float cv[MH];
+                double pv[MS];
+                float cv[MS];
 #pragma unroll
-                for (int m = 0; m < MH; m++) {
+                for (int m = 0; m < MS; m++) {
                     pv[m] = cs[m_ok[m] ? cpos + m_off[m] : CS_W * CS_W];
                     cv[m] = planes[m_plb[m] + ppos];
                 }
@@ -478,29 +492,38 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
                 const bool general = node && xx >= 1 && yy >= 1 && (a - 2) < A;
                 DpMerge best{inf, 0x7fffffff};
 #pragma unroll
-                for (int m = 0; m < MH; m++) {
+                for (int m = 0; m < MS; m++) {
                     const double tot = pv[m] + (m_del[m] ? pen : (double)cv[m]);
                     const bool take = tot < best.tot;
                     best.tot = take ? tot : best.tot;
                     best.key = take ? m_key[m] : best.key;
                 }
+                // merge over the node's eight lanes: lane ^ 1, lane ^ 2 (quad permutes), then the other quad (half-row mirror)
+#define TILE_MERGE(CTRL)                                                                                                      \
+    {                                                                                                                         \
+        const unsigned long long u_ = __double_as_longlong(best.tot);                                                         \
+        const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u_, CTRL, 0xf, 0xf, false);               \
+        const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u_ >> 32), CTRL, 0xf, 0xf, false);       \
+        const int ok_ = __builtin_amdgcn_update_dpp(0, best.key, CTRL, 0xf, 0xf, false);                                       \
+        const double ot_ = __longlong_as_double(((unsigned long long)hi_ << 32) | lo_);                                       \
+        const bool tk_ = ot_ < best.tot || (ot_ == best.tot && ok_ < best.key);                                               \
+        best.tot = tk_ ? ot_ : best.tot;                                                                                      \
+        best.key = tk_ ? ok_ : best.key;                                                                                      \
+    }
+                TILE_MERGE(0xB1)   // quad_perm [1,0,3,2]
+                TILE_MERGE(0x4E)   // quad_perm [2,3,0,1]
+                TILE_MERGE(0x141)  // row_half_mirror: lane k of an 8-lane group <-> lane 7 - k (the other quad)
+#undef TILE_MERGE
                 if (!general) { best.tot = inf; best.key = 0x7fffffff; }
-                {   // merge the two halves by (total, move index)
-                    const unsigned long long u = __double_as_longlong(best.tot);
-                    const unsigned ol = xchg32_u32((unsigned)u, lane), oh = xchg32_u32((unsigned)(u >> 32), lane);
-                    const double ot = __longlong_as_double(((unsigned long long)oh << 32) | ol);
-                    const int ok = (int)xchg32_u32((unsigned)best.key, lane);
-                    if (ot < best.tot || (ot == best.tot && ok < best.key)) { best.tot = ot; best.key = ok; }
-                }
                 double v = best.key != 0x7fffffff ? best.tot : inf;
                 int bx = best.key != 0x7fffffff ? (best.key & 255) : -1, by = best.key != 0x7fffffff ? ((best.key >> 8) & 255) : -1;
                 if (node && xx == 0) { v = pen * (double)yy; bx = 0; by = 1; }
                 else if (node && yy == 0) { v = pen * (double)xx; bx = 1; by = 0; }
-                if (inside && half == 0) {
+                if (inside && slot == 0) {
                     cs[cpos] = node ? v : inf;
                     bpt[ppos] = (!node || bx < 0) ? (unsigned char)0xFF : (unsigned char)((bx << 4) | by);
                 }
-                asm volatile("" ::: "memory");   // (keep the next diagonal's reads behind these writes in program order)
+                __syncthreads();   // the diagonal is complete before any wave reads it
             }
         }
         __syncthreads();
@@ -589,7 +612,7 @@ int svxl_band_tiles_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, co
     }
 #define TILES(E)                                                                                                                   \
     do {                                                                                                                           \
-        if (small) hipLaunchKernelGGL((k_band_tiles<E, 8, 5, 3>), grid, dim3(TT_THREADS), 0, st, pairs, n_pairs, types, plan, W, max_nd, gpref, ticket, prof); \
+        if (small) hipLaunchKernelGGL((k_band_tiles<E, 8, 5, 5>), grid, dim3(TT_THREADS), 0, st, pairs, n_pairs, types, plan, W, max_nd, gpref, ticket, prof); \
         else hipLaunchKernelGGL((k_band_tiles<E, 12, 8, 2>), grid, dim3(TT_THREADS), 0, st, pairs, n_pairs, types, plan, W, max_nd, gpref, ticket, prof); \
     } while (0)
     if (dtype == SVX_F32) TILES(ElemF32);
