@@ -304,6 +304,10 @@ __global__ __launch_bounds__(256) void k_knob_sort(const SvxPairDev* __restrict_
     }
 }
 
+// Target rows in flight per wave in k_knob_scores. Measured on the 1024-pair batch (levels >= 1, fp32): 1 -> 15.3 ms,
+// 2 -> 14.9 ms, 3 -> 16.6 ms, 4 -> 16.6 ms, 6 -> 18.6 ms: past 2 the registers cost more waves than the depth gains.
+constexpr int KNOB_PF = 2;  // target rows in flight per wave in k_knob_scores
+
 // One wave per source row x: the row stays in registers while the wave walks the samples (x, y_s).
 // The grid is 1-D over (pair, level) tasks x `bpt` workgroups; after the XCD remap a task's workgroups
 // share one XCD, so the randomly gathered target rows of that level are served by one L2 instead of
@@ -341,41 +345,61 @@ __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restric
         }
         const float nx = Lv.nrm[0][x];
         const float ix = LV0 ? inv1[x] : 1.0f;
-        // sample ids / target rows are read one sample ahead, the target row itself is in flight while the
-        // previous dot product is reduced: one memory round trip per sample instead of three
-        int i_cur = Lv.korder[s0], y_cur = Lv.kys[s0];
-        uint4 yraw[NCH];
+        // The wave walks its samples with PF target rows in flight (a gather is one memory round trip per sample; the
+        // register ring keeps PF of them outstanding per wave). Sample ids and target rows come 64 at a time, one per
+        // lane, and are handed round with readlane, so no per-sample index load sits in front of a row load.
+        constexpr int PF = KNOB_PF;
+        const int ns = s1 - s0;
+        for (int cb = 0; cb < ns; cb += SVX_WAVE) {
+            const int cn = min(SVX_WAVE, ns - cb);
+            const int ys_l = lane < cn ? Lv.kys[s0 + cb + lane] : 0;
+            const int is_l = lane < cn ? Lv.korder[s0 + cb + lane] : 0;
+            const float nrm_l = lane < cn ? Lv.nrm[1][ys_l] : 0.f;
+            const float inv_l = (LV0 && lane < cn) ? inv2[ys_l] : 1.f;
+            float dots_l = 0.f;
+            uint4 yraw[PF][NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const int col = (c * SVX_WAVE + lane) * E::VEC;
-            yraw[c] = col < d ? *reinterpret_cast<const uint4*>(v2 + (size_t)y_cur * d + col) : make_uint4(0, 0, 0, 0);
-        }
-        for (int s = s0; s < s1; s++) {
-            const int i = i_cur, y = y_cur;
-            const bool more = s + 1 < s1;
-            if (more) { i_cur = Lv.korder[s + 1]; y_cur = Lv.kys[s + 1]; }
-            float dot = 0.f;
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                S tmp[E::VEC];
-                __builtin_memcpy(tmp, &yraw[c], 16);
-                float yr[E::VEC];
-                load_piece<E>(tmp, yr);
-#pragma unroll
-                for (int k = 0; k < E::VEC; k++) dot += xr[c * E::VEC + k] * yr[k];
-            }
-            if (more) {
+            for (int u = 0; u < PF; u++) {
+                const int yu = __builtin_amdgcn_readlane(ys_l, u);
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     const int col = (c * SVX_WAVE + lane) * E::VEC;
-                    yraw[c] = col < d ? *reinterpret_cast<const uint4*>(v2 + (size_t)y_cur * d + col) : make_uint4(0, 0, 0, 0);
+                    yraw[u][c] = (u < cn && col < d) ? *reinterpret_cast<const uint4*>(v2 + (size_t)yu * d + col) : make_uint4(0, 0, 0, 0);
                 }
             }
-            dot = wave_sum(dot);
-            if (lane == 0) {
-                if (LV0) dot = dot * ix * inv2[y];
-                const float den = nx + Lv.nrm[1][y];  // float add, no epsilon (dp_core.pyx:161)
-                Lv.kscore[i] = (float)((2.0 * (1.0 - (double)dot)) / (double)den);
+            for (int base = 0; base < cn; base += PF) {
+#pragma unroll
+                for (int u = 0; u < PF; u++) {
+                    const int k = base + u;  // sample k of the chunk sits in slot u (PF divides base)
+                    if (k >= cn) break;      // wave-uniform
+                    float dot = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) {
+                        S tmp[E::VEC];
+                        __builtin_memcpy(tmp, &yraw[u][c], 16);
+                        float yr[E::VEC];
+                        load_piece<E>(tmp, yr);
+#pragma unroll
+                        for (int e = 0; e < E::VEC; e++) dot += xr[c * E::VEC + e] * yr[e];
+                    }
+                    if (k + PF < cn) {  // refill the slot with sample k + PF
+                        const int yn = __builtin_amdgcn_readlane(ys_l, k + PF);
+#pragma unroll
+                        for (int c = 0; c < NCH; c++) {
+                            const int col = (c * SVX_WAVE + lane) * E::VEC;
+                            yraw[u][c] = col < d ? *reinterpret_cast<const uint4*>(v2 + (size_t)yn * d + col) : make_uint4(0, 0, 0, 0);
+                        }
+                    }
+                    dot = wave_sum(dot);
+                    dots_l = lane == k ? dot : dots_l;
+                }
+            }
+            // one lane per sample finishes the chunk's scores side by side
+            if (lane < cn) {
+                float dot = dots_l;
+                if (LV0) dot = dot * ix * inv_l;
+                const float den = nx + nrm_l;  // float add, no epsilon (dp_core.pyx:161)
+                Lv.kscore[is_l] = (float)((2.0 * (1.0 - (double)dot)) / (double)den);
             }
         }
     }
