@@ -420,11 +420,13 @@ __global__ __launch_bounds__(B2_THREADS) void k_band_costs2(const SvxPairDev* __
 // ------------------------------------------------------------------------------ third generation (16-bit rows)
 // For type sets with at most 4 overlap layers per side and 10 types (alignment_max_size <= 5: the benchmark
 // configuration).  Half of a chunk's bytes -- the source rows -- never enter LDS: wave w owns source layer w >> 1,
-// x tile w & 1, and streams its 16 rows x 64 bytes per k-step straight from global memory into a register ring
+// x tile w & 1, and streams its 16 rows x 64 bytes per k-slab straight from global memory into a register ring
 // of S MFMA A-fragments; only the target rows go through the LDS ring (ky x 32 rows x 64 bytes = 8 KB per stage).
-// With the LDS ring half as wide, S = 6 stages fit beside the output image in 73 KB, so two workgroups share a CU
-// with 5 k-slabs (80 KB per workgroup) in flight instead of 2 (32 KB): the kernel is bound by bytes in flight.
-constexpr int B3_THREADS = 512, B3_ROWS = 32, B3_S = 6, B3_KX = 4, B3_KY = 4, B3_TMAX = 10;
+// S = 8 stages, filled and drained in groups of G = 2 slabs (128 adjacent bytes of every row per group, one barrier
+// per group): three groups = 96 KB per workgroup are in flight, and two workgroups share a CU (the output image
+// reuses the ring once the k loop has drained, 68 KB of LDS per workgroup).  Measured on the 1024-pair batch:
+// 6 stages, slab by slab: 17.9 ms; this shape: 17.15 ms.
+constexpr int B3_THREADS = 512, B3_ROWS = 32, B3_S = 8, B3_G = 2, B3_KX = 4, B3_KY = 4, B3_TMAX = 10;
 constexpr int B3_STAGE = B3_KY * B3_ROWS * B2_SLAB;  // 8 KB
 constexpr int B3_FS = (2 * (B3_ROWS - B2_TB) + 1) * B2_TB * B3_TMAX;
 
@@ -441,9 +443,9 @@ struct BandPlan3 {
 // s_waitcnt vmcnt(0) once per ring revolution; here the counted wait in front of the barrier is the only one).
 // Safe because nothing but this step's MFMAs reads a fragment, and they also consume the target fragments that an
 // inline-assembly statement behind the barrier delivers -- volatile statements keep their order.
-template <typename E, int NK, bool AASM>
-__device__ void band3_block(const Band2Args& g, const BandPlan3& plan, int a0, int TAe, int chunk_b, char* st0, char* st1, char* st2,
-                            char* st3, char* st4, char* st5, float* Fs, int* spx, int* spy, float* snrm, float* sinv) {
+template <typename E, int NK, bool AASM, int G>
+__device__ void band3_block(const Band2Args& g, const BandPlan3& plan, int a0, int TAe, int chunk_b, char* ring, float* Fs, int* spx,
+                            int* spy, float* snrm, float* sinv) {
     using St = typename E::storage;
     static_assert(sizeof(St) == 2, "16-bit rows");
     constexpr int ROWS = B3_ROWS, S = B3_S;
@@ -588,33 +590,41 @@ __device__ void band3_block(const Band2Args& g, const BandPlan3& plan, int a0, i
             mma_slab16<E>(acc[3][1], fa, make_uint4(b31.x, b31.y, b31.z, b31.w));
         }
     };
-    // ---- k loop.  Per slab every wave issues one DMA piece and one fragment load, in that order, so slab k's two
-    // operations are followed by two per younger slab: one counted wait covers both.
-    char* stg[6] = {st0, st1, st2, st3, st4, st5};
-    static_assert(S >= 3 && S <= 6, "ring depth");
+    // ---- k loop over groups of G slabs (G * 64 bytes of every row: the group's requests to a row are adjacent and
+    // issued back to back).  Per group every wave issues G DMA pieces and G fragment loads, so a group's 2 G
+    // operations are followed by 2 G per younger group: one counted wait in front of the barrier covers them all.
+    static_assert(S % G == 0 && NK % G == 0, "whole groups");
+    constexpr int GS = S / G, NG = NK / G;  // groups in the ring, groups in a row
+    static_assert(GS >= 3, "ring depth");
+    auto issue_group = [&](int grp) {
 #pragma unroll
-    for (int k = 0; k < S - 1; k++)
-        if (k < NK) {
-            issue_y(k, stg[k]);
-            afr[k] = load_x(k);
-        }
-    // (fully unrolled: k, the ring slots and the wait counts are constants in every copy of the body)
+        for (int u = 0; u < G; u++) issue_y(grp * G + u, ring + ((grp * G + u) % S) * B3_STAGE);
 #pragma unroll
-    for (int k = 0; k < NK; k++) {
-        const int younger = (NK - 1 - k) < (S - 2) ? (NK - 1 - k) : (S - 2);  // slabs issued after slab k
-        if (younger >= 4) wait_vm<8>();
-        else if (younger == 3) wait_vm<6>();
-        else if (younger == 2) wait_vm<4>();
-        else if (younger == 1) wait_vm<2>();
+        for (int u = 0; u < G; u++) afr[(grp * G + u) % S] = load_x(grp * G + u);
+    };
+#pragma unroll
+    for (int grp = 0; grp < GS - 1; grp++)
+        if (grp < NG) issue_group(grp);
+    // (fully unrolled: the slab numbers, the ring slots and the wait counts are constants in every copy of the body)
+#pragma unroll
+    for (int grp = 0; grp < NG; grp++) {
+        constexpr int OPS = 2 * G;
+        const int younger = (NG - 1 - grp) < (GS - 2) ? (NG - 1 - grp) : (GS - 2);  // groups issued after this one
+        if (younger >= 6) wait_vm<6 * OPS>();
+        else if (younger == 5) wait_vm<5 * OPS>();
+        else if (younger == 4) wait_vm<4 * OPS>();
+        else if (younger == 3) wait_vm<3 * OPS>();
+        else if (younger == 2) wait_vm<2 * OPS>();
+        else if (younger == 1) wait_vm<1 * OPS>();
         else wait_vm<0>();
-        __builtin_amdgcn_s_barrier();   // every wave's piece of slab k has landed; stage (k - 1) % S is free
+        __builtin_amdgcn_s_barrier();   // every wave's pieces of the group have landed; the group before it is free
         asm volatile("" ::: "memory");
-        const uint4 fa = afr[k % S];
-        if (k + S - 1 < NK) {
-            issue_y(k + S - 1, stg[(k + S - 1) % S]);
-            afr[(k + S - 1) % S] = load_x(k + S - 1);
-        }
-        mma(stg[k % S], fa);
+        uint4 fa[G];
+#pragma unroll
+        for (int u = 0; u < G; u++) fa[u] = afr[(grp * G + u) % S];
+        if (grp + GS - 1 < NG) issue_group(grp + GS - 1);
+#pragma unroll
+        for (int u = 0; u < G; u++) mma(ring + ((grp * G + u) % S) * B3_STAGE, fa[u]);
     }
     // ---- epilogue
     if (tid < 2 * B3_KX * ROWS) {
@@ -667,16 +677,13 @@ __device__ void band3_block(const Band2Args& g, const BandPlan3& plan, int a0, i
     }
 }
 
-template <typename E, int NK, bool AASM>
+template <typename E, int NK, bool AASM, int G>
 __global__ __launch_bounds__(B3_THREADS, 4) void k_band_costs3(const SvxPairDev* __restrict__ pairs, BandPlan3 plan, int T, int W, int nchunk_b,
                                                                int per_pair) {
-    __shared__ __attribute__((aligned(1024))) char st0[B3_STAGE];
-    __shared__ __attribute__((aligned(1024))) char st1[B3_STAGE];
-    __shared__ __attribute__((aligned(1024))) char st2[B3_STAGE];
-    __shared__ __attribute__((aligned(1024))) char st3[B3_STAGE];
-    __shared__ __attribute__((aligned(1024))) char st4[B3_STAGE];
-    __shared__ __attribute__((aligned(1024))) char st5[B3_STAGE];
-    __shared__ __attribute__((aligned(16))) float Fs[B3_FS];
+    // One ring of B3_S stages; the output image takes its place once the k loop has drained (B3_FS floats fit in it).
+    __shared__ __attribute__((aligned(1024))) char ring[B3_S * B3_STAGE];
+    static_assert(B3_FS * sizeof(float) <= sizeof(ring), "output image inside the ring");
+    float* Fs = reinterpret_cast<float*>(ring);
     __shared__ int spx[2 * B3_ROWS], spy[2 * B3_ROWS];
     __shared__ float snrm[2 * B3_KX * B3_ROWS], sinv[2 * B3_KX * B3_ROWS];
     const unsigned wg = xcd_remap2(blockIdx.x, gridDim.x);
@@ -704,7 +711,7 @@ __global__ __launch_bounds__(B3_THREADS, 4) void k_band_costs3(const SvxPairDev*
     g.costs = Lv.costs;
     g.boff = Lv.boff;
     g.status = P.status;
-    band3_block<E, NK, AASM>(g, plan, a0, TAe, item % nchunk_b, st0, st1, st2, st3, st4, st5, Fs, spx, spy, snrm, sinv);
+    band3_block<E, NK, AASM, G>(g, plan, a0, TAe, item % nchunk_b, ring, Fs, spx, spy, snrm, sinv);
 }
 
 bool make_plan3(const SvxTypes& ty, BandPlan3* plan) {
@@ -824,8 +831,8 @@ int svxl_band_costs2_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, i
         const bool aasm = aenv ? atoi(aenv) != 0 : true;
 #define CALL3(E, NKT)                                                                                                             \
     do {                                                                                                                          \
-        if (aasm) hipLaunchKernelGGL((k_band_costs3<E, NKT, true>), grid3, dim3(B3_THREADS), 0, ctx->stream, pairs, plan3, types.n, W, ncb3, nca3 * ncb3); \
-        else hipLaunchKernelGGL((k_band_costs3<E, NKT, false>), grid3, dim3(B3_THREADS), 0, ctx->stream, pairs, plan3, types.n, W, ncb3, nca3 * ncb3); \
+        if (aasm) hipLaunchKernelGGL((k_band_costs3<E, NKT, true, B3_G>), grid3, dim3(B3_THREADS), 0, ctx->stream, pairs, plan3, types.n, W, ncb3, nca3 * ncb3); \
+        else hipLaunchKernelGGL((k_band_costs3<E, NKT, false, B3_G>), grid3, dim3(B3_THREADS), 0, ctx->stream, pairs, plan3, types.n, W, ncb3, nca3 * ncb3); \
     } while (0)
 #define CALL3_E(E)                      \
     do {                                \
