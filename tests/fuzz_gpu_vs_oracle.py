@@ -15,7 +15,15 @@ Percentile knife-edges: with very few sampled scores (n*m below costs_sample_siz
 empirical cdf can coincide with a knot of the percentile map (2/56 == 1/28); which side np.searchsorted falls on is
 then decided by the last bit of the scores, and the deletion penalty jumps by a whole inter-sample gap.  Cases whose
 deletion penalties differ by more than 5e-5 are listed as "penalty knife-edge" with both results, not as mismatches:
-the penalty kernel itself is checked bit for bit against numpy on equal scores in tests/test_gpu_ops.py."""
+the penalty kernel itself is checked bit for bit against numpy on equal scores in tests/test_gpu_ops.py.  The same
+happens whenever sample_size * k / 28 is a whole number (500 samples at percentile 0.5: cdf == 0.5 after exactly 250
+samples): the histogram's bin width is max(scores) / 1000, and a one-ulp change of the largest score -- the size of
+the difference between two summation orders of an fp32 dot product -- moves the rounded cdf across the knot.  Checked
+on the case `--search straight --seed 5` finds (n=248, m=673): numpy's own penalty goes from 1.0040583 to 1.0026617,
+the value the GPU returns, when its largest sample is moved by one ulp.
+
+--search straight runs the same comparison for SVX_SEARCH_STRAIGHT (narrow bands, the tile sweep, and bands that
+cover the whole lattice) against make_sparse_costs / sparse_dp / sparse_traceback on the straight path."""
 import argparse
 import os
 import sys
@@ -122,13 +130,124 @@ def run_sweep(cases, seed, batch=8, verbose=True, max_size=900):
     return bad, ties, edges
 
 
+def straight_oracle(orc, v0, v1, types, W, frac, sample, nsamp, seed):
+    """make_sparse_costs + sparse_dp + sparse_traceback on the straight path with depth-0 norms and penalty."""
+    N, M = v0.shape[1], v1.shape[1]
+    a, b = v0.copy(), v1.copy()
+    orc.make_norm1(a)
+    orc.make_norm1(b)
+    rs = np.random.RandomState(seed)
+    n0, n1 = orc.compute_norms(a, b, nsamp, rs), orc.compute_norms(b, a, nsamp, rs)
+    pen, _ = orc.make_del_penalty(a[0], b[0], n0[0], n1[0], sample, frac, rs)
+    path = orc.search_path([(list(range(N)), list(range(M)))], False, N, M)
+    f, bo = orc.make_sparse_costs(a, b, n0, n1, path, types, W)
+    al, sc = orc.sparse_traceback(*orc.sparse_dp(f, bo, types, pen, N, M), N, M)
+    return al, sc, pen
+
+
+def run_straight_sweep(cases, seed, batch=6, verbose=True, max_size=500):
+    """SVX_SEARCH_STRAIGHT (band around the straight diagonal; wide bands run the tile sweep, bands that cover the
+    lattice are the dense mode) against the oracle on the same straight path.  -> (mismatches, exact ties)"""
+    import torch
+    import oracle
+    from synth import alignment_types, make_pair, round_bf16
+    from svx.vecalign import dp_utils
+    rs = np.random.RandomState(seed)
+    t0 = time.time()
+    done = bad = ties = errs = edges = 0
+    nbatch = 0
+    while done < cases:
+        K = int(rs.randint(1, 6))
+        amax = int(rs.randint(2, K + 2))
+        types = alignment_types(amax)
+        W = int(rs.choice([rs.randint(3, 33), rs.randint(33, 70), rs.randint(70, 160), max_size + 1]))
+        sample = int(rs.choice([500, 5000, 20000]))
+        nsamp = int(rs.choice([7, 100]))
+        frac = float(rs.choice([0.05, 0.2, 0.5]))
+        d = int(rs.choice([32, 64, 96, 256]))
+        store = rs.choice(["f32", "bf16", "f16"])
+        nb = min(batch, cases - done)
+        hosts, devs = [], []
+        for i in range(nb):
+            n, m = int(rs.randint(1, max_size)), int(rs.randint(1, max_size))
+            if rs.rand() < 0.1:
+                n, m = int(rs.randint(1, 12)), int(rs.randint(1, 12))
+            v0, v1 = make_pair(n, m, K, d, int(rs.randint(1 << 30)), deletions=int(rs.randint(0, 6)) if min(n, m) > 12 else 0,
+                               zero_rows=int(rs.randint(0, 3)))
+            if store == "bf16":
+                v0, v1 = round_bf16(v0), round_bf16(v1)
+                devs.append((torch.from_numpy(v0).cuda().bfloat16(), torch.from_numpy(v1).cuda().bfloat16()))
+            elif store == "f16":
+                v0, v1 = v0.astype(np.float16).astype(np.float32), v1.astype(np.float16).astype(np.float32)
+                devs.append((torch.from_numpy(v0).cuda().half(), torch.from_numpy(v1).cuda().half()))
+            else:
+                devs.append((torch.from_numpy(v0).cuda(), torch.from_numpy(v1).cuda()))
+            hosts.append((v0, v1))
+        seeds = [int(rs.randint(1 << 30)) for _ in range(nb)]
+        try:
+            res = dp_utils.align_band_batch(devs, types, frac, W, sample, nsamp, rngs=[np.random.RandomState(s) for s in seeds])
+        except Exception as e:
+            res = e
+        for i in range(nb):
+            try:
+                ref = straight_oracle(oracle, hosts[i][0], hosts[i][1], types, W, frac, sample, nsamp, seeds[i])
+            except Exception as e:
+                ref = e
+            if isinstance(res, Exception) or isinstance(ref, Exception):
+                ok = isinstance(res, Exception) and isinstance(ref, Exception)
+                errs += 1
+                if errs <= 3:
+                    print("both sides raised:" if ok else "one side raised:", repr(res)[:160], "|", repr(ref)[:160], flush=True)
+            else:
+                al, sc = res[i][0], np.asarray(res[i][1])
+                ok = al == ref[0] and (len(sc) == 0 or np.abs(sc - ref[1]).max() < 1e-4)
+                if not ok:
+                    pen = ref[2]
+
+                    def objective(alg, scores):
+                        return sum(c * len(x) * len(y) if (x and y) else pen * (len(x) + len(y)) for (x, y), c in zip(alg, scores))
+                    cover = [v for x, _ in al for v in x] == list(range(hosts[i][0].shape[1])) and \
+                        [v for _, y in al for v in y] == list(range(hosts[i][1].shape[1]))
+                    if cover and abs(objective(al, sc) - objective(ref[0], ref[1])) < 2e-6 * max(len(al), len(ref[0])):
+                        ties += 1
+                        ok = True
+                    elif cover and abs(float(res[i][2][0]) - float(pen)) > 5e-5:
+                        edges += 1
+                        ok = True
+                        print("penalty knife-edge", dict(n=hosts[i][0].shape[1], m=hosts[i][1].shape[1], sample=sample, frac=frac, store=str(store)),
+                              float(res[i][2][0]), float(pen), flush=True)
+            if not ok:
+                bad += 1
+                print("MISMATCH straight", dict(K=K, amax=amax, W=W, sample=sample, nsamp=nsamp, frac=frac, d=d, store=str(store),
+                                                n=hosts[i][0].shape[1], m=hosts[i][1].shape[1], seed=seeds[i]),
+                      repr(res)[:200] if isinstance(res, Exception) else "", repr(ref)[:200] if isinstance(ref, Exception) else "", flush=True)
+                if not isinstance(res, Exception) and not isinstance(ref, Exception):
+                    ga, ra = res[i][0], ref[0]
+                    k = next((j for j in range(min(len(ga), len(ra))) if ga[j] != ra[j]), min(len(ga), len(ra)))
+                    print("  first difference at alignment", k, "gpu", ga[max(0, k - 2):k + 4], "ref", ra[max(0, k - 2):k + 4])
+                    print("  gpu scores", [round(float(v), 6) for v in res[i][1][max(0, k - 2):k + 4]], "ref", [round(float(v), 6) for v in ref[1][max(0, k - 2):k + 4]],
+                          "pen gpu", [float(v) for v in res[i][2]], "ref", float(ref[2]), flush=True)
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_straight_%d.npz" % seeds[i]), v0=hosts[i][0], v1=hosts[i][1])
+        done += nb
+        nbatch += 1
+        if verbose and nbatch % 10 == 0:
+            print(f"{done} cases, {bad} mismatches, {ties} exact ties, {edges} penalty knife-edges, {errs} raised, {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz straight: {done} cases, {bad} mismatches, {ties} exact ties, {edges} penalty knife-edges, {errs} raised on both sides, {time.time() - t0:.0f} s")
+    return bad, ties
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--search", default="ref", choices=["ref", "straight"], help="ref: coarse-to-fine; straight: the straight band")
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--max_size", type=int, default=900, help="documents have 1 .. max_size-1 segments")
     a = ap.parse_args()
+    if a.search == "straight":
+        bad, _ = run_straight_sweep(a.cases, a.seed, min(a.batch, 6), max_size=a.max_size)
+        sys.exit(1 if bad else 0)
     bad, _, _ = run_sweep(a.cases, a.seed, a.batch, max_size=a.max_size)
     sys.exit(1 if bad else 0)
 
