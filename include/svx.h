@@ -182,6 +182,15 @@ int svx_unit_rows(svx_ctx *ctx, const void *rows, int dtype, int64_t n, int d, v
 int svx_knn_mean_sim(svx_ctx *ctx, const void *queries, int q_dtype, int64_t n, const void *db, int db_dtype,
                      int64_t n_db, int d, int k, float *mean_sim);
 
+/* The same search with the database arriving shard by shard (one rank's rows at a time on a ring of GPUs, or a
+ * corpus larger than one allocation): topk [n][k] floats holds every query's k largest similarities so far, in no
+ * particular order (-inf = none yet).  first != 0: the lists start empty; otherwise they continue from `topk`.
+ * After the call `topk` covers the shards seen so far; mean_sim (nullable) receives their mean, which after the
+ * last shard is svx_knn_mean_sim's result over the concatenated database (score_align.py:137-148, where the
+ * reference searches one index holding the whole corpus).  n_db may be smaller than k, or 0. */
+int svx_knn_topk_merge(svx_ctx *ctx, const void *queries, int q_dtype, int64_t n, const void *db, int db_dtype,
+                       int64_t n_db, int d, int k, float *topk, int first, float *mean_sim);
+
 /* score_align.py:151-160: scores[i] = <x_i/|x_i|, y_i/|y_i|> / ((mean_xy[i] + mean_yx[i]) / 2)
  * (SVX_MARGIN_RATIO) or minus it (SVX_MARGIN_DISTANCE).  x, y [n][d] of `dtype`. */
 int svx_margin_scores(svx_ctx *ctx, const void *x, const void *y, int dtype, int64_t n, int d, const float *mean_xy,

@@ -251,7 +251,8 @@ __device__ __forceinline__ void knn_tile(const char* cur, char* nxt, const uint1
 template <bool BF, typename QE, int RPW, int NW, bool KREG>
 __global__ __launch_bounds__(64 * NW, 1) void k_knn_mean(const typename QE::storage* __restrict__ q, long n,
                                                          const uint16_t* __restrict__ db, long N, int d, int k,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, const float* __restrict__ st_in,
+                                                         float* __restrict__ st_out) {
     // Two tile buffers as two LDS objects: the compiler then knows that the ds_reads of one never touch the
     // tile an LDS-DMA is still filling, and does not drain the DMA (s_waitcnt vmcnt(0)) in front of them.
     __shared__ __attribute__((aligned(16))) char tile0[KNN_DT * KNN_RS];
@@ -301,17 +302,34 @@ __global__ __launch_bounds__(64 * NW, 1) void k_knn_mean(const typename QE::stor
             qf[b][s] = v;
         }
     }
+    // The kept lists start empty (-INF) or, when the database comes shard by shard (svx_knn_topk_merge), from the
+    // lists the sweep over the earlier shards left in st_in [n][k].
     float hp[RPW][4], th[RPW][4];
 #pragma unroll
     for (int b = 0; b < RPW; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            hp[b][r] = lr < k ? -INFINITY : INFINITY;
-            th[b][r] = -INFINITY;
+            const long qrow = (long)blockIdx.x * QT + (w * RPW + b) * 16 + 4 * lg + r;
+            float v = lr < k ? -INFINITY : INFINITY;
+            if (KREG && st_in && lr < k && qrow < n) v = st_in[qrow * k + lr];
+            hp[b][r] = v;
+            th[b][r] = (KREG && st_in) ? row16_min(v) : -INFINITY;
         }
     if (!KREG) {
-        for (int i = tid; i < QT * hs; i += NT) heap[i] = (i % hs) < k ? -INFINITY : INFINITY;
-        for (int i = tid; i < QT; i += NT) thr[i] = -INFINITY;
+        for (int i = tid; i < QT * hs; i += NT) {
+            const int qi = i / hs, j = i % hs;
+            const long qrow = (long)blockIdx.x * QT + qi;
+            heap[i] = j < k ? ((st_in && qrow < n) ? st_in[qrow * k + j] : -INFINITY) : INFINITY;
+        }
+        __syncthreads();
+        for (int qi = tid; qi < QT; qi += NT) {
+            float m = -INFINITY;
+            if (st_in) {
+                m = INFINITY;
+                for (int j = 0; j < k; j++) m = fminf(m, heap[qi * hs + j]);
+            }
+            thr[qi] = m;
+        }
     }
 
     const long ntiles = (N + KNN_DT - 1) / KNN_DT;
@@ -338,7 +356,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_knn_mean(const typename QE::stor
             for (int r = 0; r < 4; r++) {
                 const float sum = row16_sum(lr < k ? hp[b][r] : 0.f);
                 const long qrow = (long)blockIdx.x * QT + (w * RPW + b) * 16 + 4 * lg + r;
-                if (lr == 0 && qrow < n) out[qrow] = sum / (float)k;
+                if (out && lr == 0 && qrow < n) out[qrow] = sum / (float)k;
+                if (st_out && lr < k && qrow < n) st_out[qrow * k + lr] = hp[b][r];
             }
     } else if (lane < 16 * RPW) {
         const int qi = w * RPW * 16 + lane;
@@ -347,7 +366,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_knn_mean(const typename QE::stor
             const float* h = heap + qi * hs;
             float sum = 0.f;
             for (int j = 0; j < k; j++) sum += h[j];
-            out[qrow] = sum / (float)k;
+            if (out) out[qrow] = sum / (float)k;
+            if (st_out)
+                for (int j = 0; j < k; j++) st_out[qrow * k + j] = h[j];
         }
     }
 }
@@ -421,7 +442,8 @@ static size_t knn_smem(int k, int rpw, int nw) {
 }
 
 template <bool BF, typename QE, int RPW, int NW, bool KREG>
-static int launch_knn_k(svx_ctx* ctx, const void* q, long n, const void* db, long N, int d, int k, float* out) {
+static int launch_knn_k(svx_ctx* ctx, const void* q, long n, const void* db, long N, int d, int k, float* out, const float* st_in,
+                        float* st_out) {
     const size_t smem = KREG ? 0 : knn_smem(k, RPW, NW);
     static size_t attr_set = 0;
     if (smem > attr_set) {
@@ -430,28 +452,30 @@ static int launch_knn_k(svx_ctx* ctx, const void* q, long n, const void* db, lon
     }
     const long qt = 16 * RPW * NW;
     k_knn_mean<BF, QE, RPW, NW, KREG><<<dim3((unsigned)((n + qt - 1) / qt)), dim3(64 * NW), smem, ctx->stream>>>(
-        reinterpret_cast<const typename QE::storage*>(q), n, reinterpret_cast<const uint16_t*>(db), N, d, k, out);
+        reinterpret_cast<const typename QE::storage*>(q), n, reinterpret_cast<const uint16_t*>(db), N, d, k, out, st_in, st_out);
     SVX_LAUNCH_CHECK(ctx, "k_knn_mean");
     return SVX_OK;
 }
 
 template <bool BF, typename QE, int RPW, int NW>
-static int launch_knn(svx_ctx* ctx, const void* q, long n, const void* db, long N, int d, int k, float* out) {
-    if (k <= 16) return launch_knn_k<BF, QE, RPW, NW, true>(ctx, q, n, db, N, d, k, out);
-    return launch_knn_k<BF, QE, RPW, NW, false>(ctx, q, n, db, N, d, k, out);
+static int launch_knn(svx_ctx* ctx, const void* q, long n, const void* db, long N, int d, int k, float* out, const float* st_in,
+                      float* st_out) {
+    if (k <= 16) return launch_knn_k<BF, QE, RPW, NW, true>(ctx, q, n, db, N, d, k, out, st_in, st_out);
+    return launch_knn_k<BF, QE, RPW, NW, false>(ctx, q, n, db, N, d, k, out, st_in, st_out);
 }
 
 // Shapes: (RPW, NW) = (1, 4): 64 queries per workgroup, for small query sets; (2, 4): 128 queries, half the LDS
 // fragment reads per MFMA, one wave per SIMD (the default for large query sets: 870 TFLOP/s at 131072^2 x 1024,
 // k = 16); (1, 8): 128 queries as two waves per SIMD (854 TFLOP/s).
 template <bool BF, typename QE>
-static int launch_knn_rpw(svx_ctx* ctx, const void* q, long n, const void* db, long N, int d, int k, float* out) {
+static int launch_knn_rpw(svx_ctx* ctx, const void* q, long n, const void* db, long N, int d, int k, float* out,
+                          const float* st_in = nullptr, float* st_out = nullptr) {
     const char* force = getenv("SVX_KNN_SHAPE");  // tuning override: "14", "18", "24"
     const int shape = force ? atoi(force) : (n >= 128 * 128 ? 24 : 14);
     const size_t tiles = (size_t)2 * KNN_DT * KNN_RS;
-    if (shape == 24 && knn_smem(k, 2, 4) + tiles <= 160 * 1024) return launch_knn<BF, QE, 2, 4>(ctx, q, n, db, N, d, k, out);
-    if (shape == 18 && knn_smem(k, 1, 8) + tiles <= 160 * 1024) return launch_knn<BF, QE, 1, 8>(ctx, q, n, db, N, d, k, out);
-    return launch_knn<BF, QE, 1, 4>(ctx, q, n, db, N, d, k, out);
+    if (shape == 24 && knn_smem(k, 2, 4) + tiles <= 160 * 1024) return launch_knn<BF, QE, 2, 4>(ctx, q, n, db, N, d, k, out, st_in, st_out);
+    if (shape == 18 && knn_smem(k, 1, 8) + tiles <= 160 * 1024) return launch_knn<BF, QE, 1, 8>(ctx, q, n, db, N, d, k, out, st_in, st_out);
+    return launch_knn<BF, QE, 1, 4>(ctx, q, n, db, N, d, k, out, st_in, st_out);
 }
 
 #define NEED(ctx, cond, ...) \
@@ -507,6 +531,31 @@ int svx_knn_mean_sim(svx_ctx* ctx, const void* queries, int q_dtype, int64_t n, 
         return bf ? launch_knn_rpw<true, ElemBF16>(ctx, queries, n, db, n_db, d, k, mean_sim)
                   : launch_knn_rpw<false, ElemBF16>(ctx, queries, n, db, n_db, d, k, mean_sim);
     default: return svx_fail(ctx, SVX_ERR_ARG, "svx_knn_mean_sim: unknown query dtype %d", q_dtype);
+    }
+}
+
+int svx_knn_topk_merge(svx_ctx* ctx, const void* queries, int q_dtype, int64_t n, const void* db, int db_dtype, int64_t n_db,
+                       int d, int k, float* topk, int first, float* mean_sim) {
+    NEED(ctx, ctx && (n == 0 || (queries && topk)) && (n_db == 0 || db), "svx_knn_topk_merge: null argument");
+    NEED(ctx, db_dtype == SVX_F16 || db_dtype == SVX_BF16, "svx_knn_topk_merge: the database is kept in fp16 or bf16 (got dtype %d)", db_dtype);
+    NEED(ctx, n >= 0 && n_db >= 0, "svx_knn_topk_merge: negative row count");
+    NEED(ctx, k >= 1 && k <= KNN_KMAX, "svx_knn_topk_merge: k = %d, supported 1..%d", k, KNN_KMAX);
+    int rc = check_margin_dim(ctx, d);
+    if (rc) return rc;
+    if (n == 0) return SVX_OK;
+    const float* st_in = first ? nullptr : topk;
+    const bool bf = db_dtype == SVX_BF16;
+    switch (q_dtype) {
+    case SVX_F32:
+        return bf ? launch_knn_rpw<true, ElemF32>(ctx, queries, n, db, n_db, d, k, mean_sim, st_in, topk)
+                  : launch_knn_rpw<false, ElemF32>(ctx, queries, n, db, n_db, d, k, mean_sim, st_in, topk);
+    case SVX_F16:
+        return bf ? launch_knn_rpw<true, ElemF16>(ctx, queries, n, db, n_db, d, k, mean_sim, st_in, topk)
+                  : launch_knn_rpw<false, ElemF16>(ctx, queries, n, db, n_db, d, k, mean_sim, st_in, topk);
+    case SVX_BF16:
+        return bf ? launch_knn_rpw<true, ElemBF16>(ctx, queries, n, db, n_db, d, k, mean_sim, st_in, topk)
+                  : launch_knn_rpw<false, ElemBF16>(ctx, queries, n, db, n_db, d, k, mean_sim, st_in, topk);
+    default: return svx_fail(ctx, SVX_ERR_ARG, "svx_knn_topk_merge: unknown query dtype %d", q_dtype);
     }
 }
 

@@ -88,6 +88,7 @@ _SIGS = {
     "svx_gather_rows": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_i64, c_vp]),
     "svx_unit_rows": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_int]),
     "svx_knn_mean_sim": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_int, c_int, c_vp]),
+    "svx_knn_topk_merge": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_int, c_int, c_vp, c_int, c_vp]),
     "svx_margin_scores": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_int, c_vp]),
     "svx_mt19937_choice": (c_int, [c_vp, ctypes.POINTER(ctypes.c_int32), c_i64, c_i64, c_vp]),
     "svx_norm_index_count": (c_i64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),

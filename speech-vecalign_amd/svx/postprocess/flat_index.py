@@ -7,8 +7,11 @@ is that database as one fp16 (or bf16) matrix on the device, searched by svx_knn
 with the per-row top-k, csrc/svx_margin.hip).  The file format is faiss' own IndexFlat serialisation
 ("IxF2"/"IxFI" + fp32 rows), read and written with `struct` -- no faiss needed, nothing is unpickled.
 
-Sharded corpora: every rank adds the rows of its own alignments and `all_gather_rows` (RCCL all-gather)
-assembles the global database on each GPU; row order is irrelevant to a mean over nearest neighbours.
+Sharded corpora: every rank adds the rows of its own alignments.  Either `all_gather_rows` (RCCL all-gather)
+assembles the global database on each GPU, or -- `ring_shards` -- the shards travel round the ring of ranks
+(point-to-point over xGMI) while every rank merges the top-k of its own queries shard by shard
+(svx_knn_topk_merge): a GPU then holds two shards instead of the corpus, and the transfer of the next shard
+overlaps the search of the current one.  Row order is irrelevant to a mean over nearest neighbours.
 """
 import ctypes
 import struct
@@ -131,6 +134,27 @@ class FlatIndex:
                                            self.d, int(k), ctypes.c_void_p(out.data_ptr())))
         return out
 
+    def merge_topk(self, queries, k: int, topk=None, want_mean: bool = False):
+        """One shard of a sharded search: merge this index's rows into the running top-k lists `topk` [n, k]
+        (None: start them) -> (topk, mean_sim or None).  The shard may hold fewer than k rows, or none."""
+        ctx = self.ctx
+        t = ctx.torch
+        q = to_device_rows(ctx, queries)
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError(f"expected [n, {self.d}] queries, got {tuple(q.shape)}")
+        first = topk is None
+        if first:
+            topk = t.empty((q.shape[0], int(k)), dtype=t.float32, device=ctx.tdev)
+        elif tuple(topk.shape) != (q.shape[0], int(k)) or topk.dtype != t.float32 or not topk.is_contiguous():
+            raise ValueError(f"topk must be a contiguous float32 [{q.shape[0]}, {k}] tensor")
+        db = self.rows
+        mean = t.empty((q.shape[0],), dtype=t.float32, device=ctx.tdev) if want_mean else None
+        ctx.check(ctx.lib.svx_knn_topk_merge(ctx.h, ctypes.c_void_p(q.data_ptr()), _torch_dtype_code(t, q.dtype), int(q.shape[0]),
+                                             ctypes.c_void_p(db.data_ptr() if db.shape[0] else None), self.code, int(db.shape[0]),
+                                             self.d, int(k), ctypes.c_void_p(topk.data_ptr()), int(first),
+                                             ctypes.c_void_p(mean.data_ptr()) if want_mean else None))
+        return topk, mean
+
     # -- files
     @classmethod
     def read(cls, path, storage: str = "fp16", device=None) -> "FlatIndex":
@@ -166,3 +190,43 @@ def all_gather_rows(local, group=None):
     dist.all_gather(parts, wire.contiguous(), group=group)
     parts = [p.view(local.dtype)[:s] for p, s in zip(parts, sizes)]
     return torch.cat(parts, dim=0)
+
+
+def ring_shards(local, group=None):
+    """Generator over every rank's [n_r, d] rows, own shard first, then the shards of ranks r-1, r-2, ... as they
+    arrive round the ring: before shard s is handed out, its forwarding to rank r+1 (and the receive of shard
+    s+1 from rank r-1) is already posted, so the caller's work on shard s overlaps the transfer.  Point-to-point
+    isend/irecv (RCCL over xGMI on GPUs; gloo in the CPU tests); fp16 / bf16 travel as raw bytes.  Yields
+    (owner_rank, rows); a rank holds its own shard and two wire buffers of the largest shard, never the corpus."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        yield (dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0), local
+        return
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(v.item()) for v in sizes]
+    cap = max(sizes)
+    if cap == 0:
+        for s in range(world):
+            yield (rank - s) % world, local
+        return
+    nxt = dist.get_global_rank(group, (rank + 1) % world) if group is not None else (rank + 1) % world
+    prv = dist.get_global_rank(group, (rank - 1) % world) if group is not None else (rank - 1) % world
+    as_wire = (lambda x: x.view(torch.uint8)) if local.dtype in (torch.float16, torch.bfloat16) else (lambda x: x)
+    row_shape = tuple(local.shape[1:])
+    bufs = [torch.zeros((cap,) + row_shape, dtype=local.dtype, device=local.device) for _ in range(2)]
+    bufs[0][:local.shape[0]] = local
+    cur = 0
+    for s in range(world):
+        owner = (rank - s) % world
+        reqs = []
+        if s + 1 < world:
+            ops = [dist.P2POp(dist.isend, as_wire(bufs[cur]), nxt, group), dist.P2POp(dist.irecv, as_wire(bufs[1 - cur]), prv, group)]
+            reqs = dist.batch_isend_irecv(ops)
+        yield owner, (local if s == 0 else bufs[cur][:sizes[owner]])
+        for r in reqs:
+            r.wait()
+        cur = 1 - cur

@@ -20,7 +20,7 @@ import numpy as np
 
 from .. import _lib
 from ..utils.file_utils import read_alignments, read_metadata
-from .flat_index import FlatIndex, all_gather_rows, to_device_rows, _torch_dtype_code
+from .flat_index import FlatIndex, all_gather_rows, ring_shards, to_device_rows, _torch_dtype_code
 from .prep_index import load_embed_from_tsv
 
 logger = logging.getLogger(__name__)
@@ -84,19 +84,52 @@ def compute_sim_with_nonflat_idx(idx_x: FlatIndex, idx_y: FlatIndex, x: np.ndarr
 
 
 def global_margin_scores(x_local, y_local, k: int = 16, margin: str = "ratio", storage: str = "fp16", group=None,
-                         device=None):
-    """Each rank passes the embeddings of ITS alignments; the databases are the union over ranks
-    (all-gather of the normalised fp16 rows), the scores come back for the local rows only."""
+                         device=None, exchange: str = "ring"):
+    """Each rank passes the embeddings of ITS alignments; the databases are the union over ranks, the scores come
+    back for the local rows only.  exchange="ring" (default): the normalised fp16 shards travel round the ring of
+    ranks and every rank merges its queries' top-k shard by shard (`ring_shards`, svx_knn_topk_merge) -- two shards
+    of HBM per GPU, transfer overlapped with search.  exchange="allgather": one RCCL all-gather, then a local
+    search of the whole corpus.  Both give the k nearest neighbours over the whole corpus."""
+    if exchange not in ("ring", "allgather"):
+        raise ValueError(f"exchange {exchange!r}: 'ring' or 'allgather'")
+    if margin not in MARGINS:
+        raise ValueError(f"Wrong margin type: {margin}")
     ctx = _lib.context(device)
+    t = ctx.torch
     d = int(x_local.shape[1])
     idx_x, idx_y = FlatIndex(d, storage, device), FlatIndex(d, storage, device)
     idx_x.add(x_local)
     idx_y.add(y_local)
-    gx, gy = FlatIndex(d, storage, device), FlatIndex(d, storage, device)
-    gx.add_unit_rows(all_gather_rows(idx_x.rows, group))
-    gy.add_unit_rows(all_gather_rows(idx_y.rows, group))
-    ctx.sync()
-    return margin_scores_device(gx, gy, x_local, y_local, k, margin)
+    if exchange == "allgather":
+        gx, gy = FlatIndex(d, storage, device), FlatIndex(d, storage, device)
+        gx.add_unit_rows(all_gather_rows(idx_x.rows, group))
+        gy.add_unit_rows(all_gather_rows(idx_y.rows, group))
+        ctx.sync()
+        return margin_scores_device(gx, gy, x_local, y_local, k, margin)
+    xd, yd = to_device_rows(ctx, x_local), to_device_rows(ctx, y_local)
+    assert xd.shape == yd.shape, f"{tuple(xd.shape)} {tuple(yd.shape)}"
+    if yd.dtype != xd.dtype:
+        yd = yd.to(xd.dtype)
+    means, totals = [], []
+    for queries, index in ((xd, idx_y), (yd, idx_x)):  # x among the targets, y among the sources
+        topk, mean, total = None, None, 0
+        ctx.sync()  # the shard rows are complete before the communication stream reads them
+        for _, rows in ring_shards(index.rows, group):
+            shard = FlatIndex(d, storage, device)
+            shard.add_unit_rows(rows)
+            topk, mean = shard.merge_topk(queries, k, topk, want_mean=True)
+            total += int(rows.shape[0])
+            ctx.sync()  # the search has read the shard before its buffer receives the next one
+        means.append(mean)
+        totals.append(total)
+    if min(totals) < k:
+        raise ValueError(f"the corpus has {min(totals)} rows on one side, fewer than k = {k}")
+    out = t.empty((xd.shape[0],), dtype=t.float32, device=ctx.tdev)
+    ctx.check(ctx.lib.svx_margin_scores(ctx.h, ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(yd.data_ptr()),
+                                        _torch_dtype_code(t, xd.dtype), int(xd.shape[0]), int(xd.shape[1]),
+                                        ctypes.c_void_p(means[0].data_ptr()), ctypes.c_void_p(means[1].data_ptr()),
+                                        MARGINS[margin], ctypes.c_void_p(out.data_ptr())))
+    return out
 
 
 def _dist_rank_world():

@@ -183,9 +183,35 @@ def test_cli_end_to_end(orc, tmp_path):
     assert np.abs(np.array(got, np.float32) - want).max() < 1e-5   # (index rows went through an fp32 file)
 
 
+@pytest.mark.parametrize("storage,k,n,shards", [("fp16", 16, 700, [300, 0, 5, 395]), ("bf16", 8, 260, [3, 257]),
+                                                 ("fp16", 40, 500, [20, 30, 450]), ("fp16", 16, 20000, [7000, 13000])])
+def test_knn_topk_merge_shard_by_shard(orc, t, storage, k, n, shards):
+    """svx_knn_topk_merge: the database handed over shard by shard (shards smaller than k, an empty shard, k > 16: the
+    LDS lists) leaves the same k nearest neighbours as one search of the whole database -- the kept similarities are
+    the same set, so the means agree to the summation order of k fp32 values -- and agrees with the oracle."""
+    from svx.postprocess.flat_index import FlatIndex
+    d = 256
+    db = unit_rows(n, d, 21)
+    q = unit_rows(333, d, 22)
+    whole = make_index(db, storage)
+    want = whole.mean_sim(q, k).cpu().numpy()
+    topk, mean, lo = None, None, 0
+    for m in shards:
+        part = FlatIndex(d=d, storage=storage)
+        part.add_unit_rows(whole.rows[lo:lo + m])
+        topk, mean = part.merge_topk(q, k, topk, want_mean=True)
+        lo += m
+    assert lo == n
+    got = mean.cpu().numpy()
+    assert np.abs(got - want).max() < 2e-7
+    assert np.allclose(np.sort(topk.cpu().numpy(), axis=1).mean(axis=1), want, atol=2e-7)
+    assert np.abs(got - orc.knn_mean_sim(q, stored(orc, db, storage), k, storage)).max() < TOL[storage]
+
+
 def test_global_margin_over_rccl():
-    """BASELINE configs[4]'s exchange on real devices: one process per GPU, the ranks' unit rows all-gathered over RCCL
-    (svx.postprocess.flat_index.all_gather_rows), every rank scoring its own shard against the union.  Needs two
+    """BASELINE configs[4]'s exchange on real devices: one process per GPU, every rank scoring its own shard against the
+    union of all ranks' unit rows -- once with the shards travelling round the ring (ring_shards + svx_knn_topk_merge,
+    point-to-point over RCCL) and once all-gathered (all_gather_rows); both against one GPU holding everything.  Needs two
     visible GPUs (the driver's one-GPU box skips it; gloo covers the logic on CPU in tests/test_margin_cpu.py)."""
     import os
     import subprocess
@@ -200,4 +226,4 @@ def test_global_margin_over_rccl():
                           "--master-port", "29671", os.path.join(os.path.dirname(__file__), "rccl_margin_worker.py")],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "RCCL_MARGIN max|diff|" in out.stdout
+    assert "RCCL_MARGIN ring max|diff|" in out.stdout and "RCCL_MARGIN allgather max|diff|" in out.stdout

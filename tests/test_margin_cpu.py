@@ -160,3 +160,60 @@ def test_global_database_all_gather_gloo(orc, world):
         want = orc.margin_scores(x_all, y_all, dbx, dby, 8, "ratio", storage)
         got = np.concatenate([g[storage] for g in gathered])
         assert np.array_equal(got, want)
+
+
+def _ring_worker(rank, world, port, q):
+    for p in (os.path.join(ROOT, "speech-vecalign_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from svx.postprocess.flat_index import ring_shards
+    sizes = [23, 0, 41][:world] if world == 3 else [23, 41][:world]
+    lo = sum(sizes[:rank])
+    x_all, y_all = unit_rows(sum(sizes), 64, 11, 6), unit_rows(sum(sizes), 64, 12, 6)
+    x, y = x_all[lo:lo + sizes[rank]], y_all[lo:lo + sizes[rank]]
+    out = {}
+    for storage, tdt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        sx = torch.from_numpy(oracle.round_storage(oracle.normalize_l2(x), storage)).to(tdt)
+        sy = torch.from_numpy(oracle.round_storage(oracle.normalize_l2(y), storage)).to(tdt)
+        owners, px, py = [], [], []
+        for owner, rows in ring_shards(sx, None):
+            owners.append(owner)
+            assert rows.dtype == tdt and rows.shape == (sizes[owner], 64)
+            px.append((owner, rows.clone()))   # (the wire buffer is reused two steps later)
+        for owner, rows in ring_shards(sy, None):
+            py.append((owner, rows.clone()))
+        assert owners == [(rank - s) % world for s in range(world)]   # own shard first, then round the ring
+        gx = torch.cat([r for _, r in sorted(px, key=lambda t: t[0])])
+        gy = torch.cat([r for _, r in sorted(py, key=lambda t: t[0])])
+        out[storage] = oracle.margin_scores(x, y, gx.float().numpy(), gy.float().numpy(), 8, "ratio", storage)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, out)
+    if rank == 0:
+        q.put(gathered)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_global_database_ring_gloo(orc, world):
+    """The ring exchange (svx.postprocess.flat_index.ring_shards): every rank sees every rank's shard exactly once,
+    its own first and then those of ranks r-1, r-2, ... (one of them possibly empty), bit-identical rows; scoring
+    against their union equals the single-process result."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, 29650 + world, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = 64
+    x_all, y_all = unit_rows(n, 64, 11, 6), unit_rows(n, 64, 12, 6)
+    for storage in ("fp16", "bf16"):
+        dbx = orc.round_storage(orc.normalize_l2(x_all), storage)
+        dby = orc.round_storage(orc.normalize_l2(y_all), storage)
+        want = orc.margin_scores(x_all, y_all, dbx, dby, 8, "ratio", storage)
+        got = np.concatenate([g[storage] for g in gathered])
+        assert np.array_equal(got, want)
