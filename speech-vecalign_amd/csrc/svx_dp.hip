@@ -389,8 +389,10 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
     constexpr int DPF_TPL = TPLT > 0 ? TPLT : 1;
     constexpr bool unrolled = TPLT > 0;  // the launcher picks TPLT = ceil(T / G) when it is <= 6
     constexpr int LB = 64 / G;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int A = g.A, B = g.B, Aout = A + 2, T = ty.n, NTt = ty.n + 2, RD = ty.maxstep + 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the sweep's loop counters and offsets stay on the SALU
+    // (g.A comes out of a vector load of the pair's path length: make it, and every count derived from it, scalar)
+    const int A = __builtin_amdgcn_readfirstlane(g.A), B = g.B, Aout = A + 2, T = ty.n, NTt = ty.n + 2, RD = ty.maxstep + 1;
     const int b = lane & (LB - 1), grp = lane / LB;
     const int Tn = T > 0 ? T : 1;
     double* ring = reinterpret_cast<double*>(smem);
@@ -417,11 +419,14 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
     // this lane's alignment types: offsets into one diagonal's [T][B] tables and merge keys
     int toff[DPF_TPL], tkey[DPF_TPL];
     bool tval[DPF_TPL];
+    int tand[DPF_TPL], tor[DPF_TPL];  // slot = (idx[o] & tand) | tor: the table entry, or the +inf slot for a type this lane does not have
 #pragma unroll
     for (int j = 0; j < DPF_TPL; j++) {
         const int t = grp + G * j;
         const int tc = t < T ? t : Tn - 1;
         tval[j] = t < T;
+        tand[j] = tval[j] ? 0xffff : 0;
+        tor[j] = tval[j] ? 0 : RD * B;
         toff[j] = tc * B + bb;
         tkey[j] = (t << 16) | (tpk[tc < NTt ? tc : 0] & 0xffff);  // ordered by t; carries (xo, yo) through the merge
     }
@@ -444,15 +449,20 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
             struct Part { double tot; int key; };
             // group merge of one lane's best type move (shared by both sweeps below)
             auto merge = [&](Part r) {
+                // (bitwise | and &: no short-circuit, so the comparisons stay mask arithmetic instead of exec branches)
                 if (G == 4) {
                     const double ob = xchg16_f64(r.tot, lane);
                     const int ok2 = (int)xchg16_u32((unsigned)r.key, lane);
-                    if (ob < r.tot || (ob == r.tot && ok2 < r.key)) { r.tot = ob; r.key = ok2; }
+                    const bool take = (ob < r.tot) | ((ob == r.tot) & (ok2 < r.key));
+                    r.tot = take ? ob : r.tot;
+                    r.key = take ? ok2 : r.key;
                 }
                 if (G >= 2) {
                     const double ob = xchg32_f64(r.tot, lane);
                     const int ok2 = (int)xchg32_u32((unsigned)r.key, lane);
-                    if (ob < r.tot || (ob == r.tot && ok2 < r.key)) { r.tot = ob; r.key = ok2; }
+                    const bool take = (ob < r.tot) | ((ob == r.tot) & (ok2 < r.key));
+                    r.tot = take ? ob : r.tot;
+                    r.key = take ? ok2 : r.key;
                 }
                 return r;
             };
@@ -477,8 +487,11 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
                 if (s10 < B && t10 < best) { best = t10; bk = key10; }
                 // borders cost pen * a; nodes outside the lattice and unreachable nodes are +inf / "none"
                 const double border = pen * (double)a;
-                best = kind == 0 ? (bk != 0x7fffffff ? best : inf) : (kind == 3 ? inf : border);
-                bk = kind == 0 ? bk : (kind == 1 ? key01 : (kind == 2 ? key10 : 0x7fffffff));
+                const bool k0 = kind == 0, k3 = kind == 3, none = bk == 0x7fffffff;
+                const double general = none ? inf : best, edge = k3 ? inf : border;
+                best = k0 ? general : edge;
+                const int ekey = kind == 1 ? key01 : (kind == 2 ? key10 : 0x7fffffff);
+                bk = k0 ? bk : ekey;
                 if (b < B && grp == 0) {
                     ring[slot * B + b] = best;
                     obest[i * B + b] = best;
@@ -503,8 +516,8 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
                     for (int j = 0; j < DPF_TPL; j++) {
                         const int o = toff[j];
                         cs0[j] = cost[o];
-                        pv0[j] = ring[tval[j] ? (int)idx[o] : RD * B];
-                        sl1[j] = tval[j] ? (int)idx[i1 * TB + o] : RD * B;
+                        pv0[j] = ring[((int)idx[o] & tand[j]) | tor[j]];
+                        sl1[j] = ((int)idx[i1 * TB + o] & tand[j]) | tor[j];
                         cs1[j] = cost[i1 * TB + o];
                     }
 #pragma unroll
@@ -518,7 +531,7 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
                 unsigned nw1 = node[(nrows > 1 ? 1 : 0) * B + bb];
                 for (int a = a0; a < a_end; a++) {
                     const int i = a - a0;
-                    const int i2 = i + 2 < nrows ? i + 2 : nrows - 1;  // (past the chunk: re-read its last row, unused)
+                    const int i2 = __builtin_amdgcn_readfirstlane(i + 2 < nrows ? i + 2 : nrows - 1);  // (past the chunk: re-read its last row, unused)
                     const int s01 = (nw >> 2) & 127, s10 = (nw >> 9) & 127;
                     const double p01 = __shfl(cur, gbase + (s01 < B ? s01 : bb), SVX_WAVE);
                     const double p10 = __shfl(cur, gbase + (s10 < B ? s10 : bb), SVX_WAVE);
@@ -529,7 +542,7 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
                     for (int j = 0; j < DPF_TPL; j++) {
                         pv[j] = ring[sl1[j]];
                         const int o = i2 * TB + toff[j];
-                        sl2[j] = tval[j] ? (int)idx[o] : RD * B;
+                        sl2[j] = ((int)idx[o] & tand[j]) | tor[j];
                         cs2[j] = cost[o];
                     }
                     const unsigned nw2 = node[i2 * B + bb];
@@ -545,7 +558,7 @@ __device__ void sparse_dp_fast(const SparseDpArgs& g, const SvxTypes& ty, int CH
                     for (int j = 0; j < DPF_TPL; j++) { sl1[j] = sl2[j]; cs1[j] = cs2[j]; }
                     nw = nw1;
                     nw1 = nw2;
-                    slot = (slot + 1 == RD) ? 0 : slot + 1;
+                    slot = __builtin_amdgcn_readfirstlane((slot + 1 == RD) ? 0 : slot + 1);
                     __builtin_amdgcn_wave_barrier();
                 }
             } else {
