@@ -396,7 +396,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "dense"])
     ap.add_argument("--band", type=int, default=2048, help="c4: band width (cells per diagonal) around the straight diagonal")
-    ap.add_argument("--pairs", type=int, default=None, help="document pairs per GPU per step (default 1024 for c2, 128 for c3)")
+    ap.add_argument("--pairs", type=int, default=None, help="document pairs per GPU per step (default 1024: BASELINE configs[1] and [2])")
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--d", type=int, default=1024)
@@ -459,7 +459,7 @@ def main():
     W = int(np.ceil(K / 2.0)) + 5
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     esz = 4 if args.dtype == "f32" else 2
-    P = args.pairs if args.pairs is not None else (1024 if args.workload == "c2" else 128)
+    P = args.pairs if args.pairs is not None else 1024
     free_b, _total_b = torch.cuda.mem_get_info(dev)
     if args.workload == "c2":
         shapes = [(N, M)] * P
