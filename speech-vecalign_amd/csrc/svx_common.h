@@ -37,6 +37,65 @@ struct ElemBF16 {
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ float f16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 
+// ---- accesses through global-address-space pointers.  The batch kernels take their pointers out of SvxPairDev
+// records in memory, which the compiler can only type as generic: a dereference becomes flat_load / flat_store,
+// which count against vmcnt AND lgkmcnt, so every wait for an LDS read also drains the row loads in flight (the
+// ISA showed nothing but `s_waitcnt vmcnt(0) lgkmcnt(0)`).  Device buffers are global memory: say so at the access.
+#define SVX_GLOBAL(T) __attribute__((address_space(1))) T
+typedef uint32_t svx_u32x4 __attribute__((ext_vector_type(4)));
+typedef float svx_f32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ T gld(const T* p) { return *(const SVX_GLOBAL(T)*)p; }
+template <typename T>
+__device__ __forceinline__ void gst(T* p, T v) { *(SVX_GLOBAL(T)*)p = v; }
+__device__ __forceinline__ uint4 gld16(const void* p) {
+    const svx_u32x4 v = *(const SVX_GLOBAL(svx_u32x4)*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 gldf4(const float* p) {
+    const svx_f32x4 v = *(const SVX_GLOBAL(svx_f32x4)*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gstf4(float* p, float a, float b, float c, float d) {
+    const svx_f32x4 v = {a, b, c, d};
+    *(SVX_GLOBAL(svx_f32x4)*)p = v;
+}
+__device__ __forceinline__ void gstf4_nt(float* p, float a, float b, float c, float d) {  // streaming store
+    const svx_f32x4 v = {a, b, c, d};
+    __builtin_nontemporal_store(v, (SVX_GLOBAL(svx_f32x4)*)p);
+}
+
+// Widen one 16-byte piece held in registers to VEC floats.
+template <typename E>
+__device__ __forceinline__ void decode_piece(const uint4& v, float* out);
+template <>
+__device__ __forceinline__ void decode_piece<ElemF32>(const uint4& v, float* out) {
+    out[0] = __uint_as_float(v.x); out[1] = __uint_as_float(v.y); out[2] = __uint_as_float(v.z); out[3] = __uint_as_float(v.w);
+}
+template <>
+__device__ __forceinline__ void decode_piece<ElemF16>(const uint4& v, float* out) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        out[2 * i] = f16_to_f32((uint16_t)(w[i] & 0xffffu));
+        out[2 * i + 1] = f16_to_f32((uint16_t)(w[i] >> 16));
+    }
+}
+template <>
+__device__ __forceinline__ void decode_piece<ElemBF16>(const uint4& v, float* out) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        out[2 * i] = __uint_as_float(w[i] << 16);
+        out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+// One 16-byte piece out of global memory, widened.
+template <typename E>
+__device__ __forceinline__ void gload_piece(const typename E::storage* p, float* out) {
+    decode_piece<E>(gld16(p), out);
+}
+
 // Load one 16-byte piece and widen to VEC floats.
 template <typename E>
 __device__ __forceinline__ void load_piece(const typename E::storage* p, float* out);

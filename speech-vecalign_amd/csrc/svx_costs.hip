@@ -330,21 +330,21 @@ __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restric
     const float* inv1 = LV0 ? Lv.inv[0] : nullptr;
     const float* inv2 = LV0 ? Lv.inv[1] : nullptr;
     for (int x = blk * 4 + (threadIdx.x >> 6); x < n; x += bpt * 4) {
-        const int s0 = Lv.kstart[x], s1 = Lv.kstart[x + 1];
+        const int s0 = gld(Lv.kstart + x), s1 = gld(Lv.kstart + x + 1);
         if (s0 >= s1) continue;  // wave-uniform
         float xr[EPL];
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             const int col = (c * SVX_WAVE + lane) * E::VEC;
             if (col < d) {
-                load_piece<E>(v1 + (size_t)x * d + col, xr + c * E::VEC);
+                gload_piece<E>(v1 + (size_t)x * d + col, xr + c * E::VEC);
             } else {
 #pragma unroll
                 for (int i = 0; i < E::VEC; i++) xr[c * E::VEC + i] = 0.f;
             }
         }
-        const float nx = Lv.nrm[0][x];
-        const float ix = LV0 ? inv1[x] : 1.0f;
+        const float nx = gld(Lv.nrm[0] + x);
+        const float ix = LV0 ? gld(inv1 + x) : 1.0f;
         // The wave walks its samples with PF target rows in flight (a gather is one memory round trip per sample; the
         // register ring keeps PF of them outstanding per wave). Sample ids and target rows come 64 at a time, one per
         // lane, and are handed round with readlane, so no per-sample index load sits in front of a row load.
@@ -352,10 +352,10 @@ __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restric
         const int ns = s1 - s0;
         for (int cb = 0; cb < ns; cb += SVX_WAVE) {
             const int cn = min(SVX_WAVE, ns - cb);
-            const int ys_l = lane < cn ? Lv.kys[s0 + cb + lane] : 0;
-            const int is_l = lane < cn ? Lv.korder[s0 + cb + lane] : 0;
-            const float nrm_l = lane < cn ? Lv.nrm[1][ys_l] : 0.f;
-            const float inv_l = (LV0 && lane < cn) ? inv2[ys_l] : 1.f;
+            const int ys_l = lane < cn ? gld(Lv.kys + s0 + cb + lane) : 0;
+            const int is_l = lane < cn ? gld(Lv.korder + s0 + cb + lane) : 0;
+            const float nrm_l = lane < cn ? gld(Lv.nrm[1] + ys_l) : 0.f;
+            const float inv_l = (LV0 && lane < cn) ? gld(inv2 + ys_l) : 1.f;
             float dots_l = 0.f;
             uint4 yraw[PF][NCH];
 #pragma unroll
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restric
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     const int col = (c * SVX_WAVE + lane) * E::VEC;
-                    yraw[u][c] = (u < cn && col < d) ? *reinterpret_cast<const uint4*>(v2 + (size_t)yu * d + col) : make_uint4(0, 0, 0, 0);
+                    yraw[u][c] = (u < cn && col < d) ? gld16(v2 + (size_t)yu * d + col) : make_uint4(0, 0, 0, 0);
                 }
             }
             for (int base = 0; base < cn; base += PF) {
@@ -375,10 +375,8 @@ __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restric
                     float dot = 0.f;
 #pragma unroll
                     for (int c = 0; c < NCH; c++) {
-                        S tmp[E::VEC];
-                        __builtin_memcpy(tmp, &yraw[u][c], 16);
                         float yr[E::VEC];
-                        load_piece<E>(tmp, yr);
+                        decode_piece<E>(yraw[u][c], yr);
 #pragma unroll
                         for (int e = 0; e < E::VEC; e++) dot += xr[c * E::VEC + e] * yr[e];
                     }
@@ -387,7 +385,7 @@ __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restric
 #pragma unroll
                         for (int c = 0; c < NCH; c++) {
                             const int col = (c * SVX_WAVE + lane) * E::VEC;
-                            yraw[u][c] = col < d ? *reinterpret_cast<const uint4*>(v2 + (size_t)yn * d + col) : make_uint4(0, 0, 0, 0);
+                            yraw[u][c] = col < d ? gld16(v2 + (size_t)yn * d + col) : make_uint4(0, 0, 0, 0);
                         }
                     }
                     dot = wave_sum(dot);
@@ -399,7 +397,7 @@ __global__ __launch_bounds__(256) void k_knob_scores(const SvxPairDev* __restric
                 float dot = dots_l;
                 if (LV0) dot = dot * ix * inv_l;
                 const float den = nx + nrm_l;  // float add, no epsilon (dp_core.pyx:161)
-                Lv.kscore[is_l] = (float)((2.0 * (1.0 - (double)dot)) / (double)den);
+                gst(Lv.kscore + is_l, (float)((2.0 * (1.0 - (double)dot)) / (double)den));
             }
         }
     }

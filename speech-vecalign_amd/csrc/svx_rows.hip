@@ -27,7 +27,7 @@ struct Row {
         for (int c = 0; c < NCH; c++) {
             int col = (c * SVX_WAVE + lane) * VEC;
             if (col < d) {
-                load_piece<E>(row + col, x + c * VEC);
+                gload_piece<E>(row + col, x + c * VEC);
             } else {
 #pragma unroll
                 for (int i = 0; i < VEC; i++) x[c * VEC + i] = 0.f;
@@ -42,7 +42,7 @@ struct Row {
             if (col < d) {
 #pragma unroll
                 for (int q = 0; q < VEC / 4; q++) {
-                    float4 t = *reinterpret_cast<const float4*>(v + col + 4 * q);
+                    float4 t = gldf4(v + col + 4 * q);
                     x[c * VEC + 4 * q + 0] = t.x; x[c * VEC + 4 * q + 1] = t.y;
                     x[c * VEC + 4 * q + 2] = t.z; x[c * VEC + 4 * q + 3] = t.w;
                 }
@@ -59,24 +59,20 @@ struct Row {
             if (col < d) {
 #pragma unroll
                 for (int q = 0; q < VEC / 4; q++) {
-                    float4 t = make_float4(x[c * VEC + 4 * q + 0], x[c * VEC + 4 * q + 1], x[c * VEC + 4 * q + 2],
-                                           x[c * VEC + 4 * q + 3]);
-                    *reinterpret_cast<float4*>(v + col + 4 * q) = t;
+                    gstf4(v + col + 4 * q, x[c * VEC + 4 * q + 0], x[c * VEC + 4 * q + 1], x[c * VEC + 4 * q + 2], x[c * VEC + 4 * q + 3]);
                 }
             }
         }
     }
     // streaming store: written once, read by a later kernel after tens of GB of other traffic
     __device__ static __forceinline__ void storef_nt(float* v, int d, int lane, const float* x) {
-        typedef float f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             int col = (c * SVX_WAVE + lane) * VEC;
             if (col < d) {
 #pragma unroll
                 for (int q = 0; q < VEC / 4; q++) {
-                    f4 t = {x[c * VEC + 4 * q + 0], x[c * VEC + 4 * q + 1], x[c * VEC + 4 * q + 2], x[c * VEC + 4 * q + 3]};
-                    __builtin_nontemporal_store(t, reinterpret_cast<f4*>(v + col + 4 * q));
+                    gstf4_nt(v + col + 4 * q, x[c * VEC + 4 * q + 0], x[c * VEC + 4 * q + 1], x[c * VEC + 4 * q + 2], x[c * VEC + 4 * q + 3]);
                 }
             }
         }
@@ -100,7 +96,7 @@ __device__ __forceinline__ void pair_row(const typename E::storage* rows0, const
     float a[R::EPL], b[R::EPL];
     R::load(rows0 + (size_t)(2 * r) * d, d, lane, a);
     R::load(rows0 + (size_t)(2 * r + 1) * d, d, lane, b);
-    const float ia = inv0[2 * r], ib = inv0[2 * r + 1];
+    const float ia = gld(inv0 + 2 * r), ib = gld(inv0 + 2 * r + 1);
 #pragma unroll
     for (int e = 0; e < R::EPL; e++) {
         const float pa = a[e] * ia, pb = b[e] * ib;
@@ -125,34 +121,29 @@ __device__ __forceinline__ void fetch_raw(const typename E::storage* rows, const
         const int col = (c * SVX_WAVE + lane) * VEC;
         const bool in = col < d;
         if (PAIR) {
-            out.p[c] = in ? *reinterpret_cast<const uint4*>(rows + (size_t)(2 * r) * d + col) : make_uint4(0, 0, 0, 0);
-            out.p[NCH + c] = in ? *reinterpret_cast<const uint4*>(rows + (size_t)(2 * r + 1) * d + col) : make_uint4(0, 0, 0, 0);
+            out.p[c] = in ? gld16(rows + (size_t)(2 * r) * d + col) : make_uint4(0, 0, 0, 0);
+            out.p[NCH + c] = in ? gld16(rows + (size_t)(2 * r + 1) * d + col) : make_uint4(0, 0, 0, 0);
         } else {
-            out.p[c] = in ? *reinterpret_cast<const uint4*>(rows + (size_t)r * d + col) : make_uint4(0, 0, 0, 0);
+            out.p[c] = in ? gld16(rows + (size_t)r * d + col) : make_uint4(0, 0, 0, 0);
         }
     }
     if (PAIR) {
-        out.ia = inv0[2 * r];
-        out.ib = inv0[2 * r + 1];
+        out.ia = gld(inv0 + 2 * r);
+        out.ib = gld(inv0 + 2 * r + 1);
     }
 }
 
 template <typename E, int NCH, bool PAIR>
 __device__ __forceinline__ void decode_raw(const RawRow<E, NCH, PAIR>& in, float* x) {
 #pragma clang fp contract(off)
-    using S = typename E::storage;
     constexpr int VEC = E::VEC;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-        S tmp[VEC];
-        __builtin_memcpy(tmp, &in.p[c], 16);
         float a[VEC];
-        load_piece<E>(tmp, a);
+        decode_piece<E>(in.p[c], a);
         if (PAIR) {
-            S tmp2[VEC];
-            __builtin_memcpy(tmp2, &in.p[NCH + c], 16);
             float b[VEC];
-            load_piece<E>(tmp2, b);
+            decode_piece<E>(in.p[NCH + c], b);
 #pragma unroll
             for (int i = 0; i < VEC; i++) {
                 const float pa = a[i] * in.ia, pb = b[i] * in.ib;  // the two products and the sum of pair_row
@@ -186,8 +177,8 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
         const int ch = c / (SVX_WAVE * E::VEC), l = (c / E::VEC) % SVX_WAVE, i = c % E::VEC;
         const int e = ch * E::VEC + i;
         const int at = ((e >> 2) * SVX_WAVE + l) * 4 + (e & 3);
-        mu_l[at] = (mean && c < d) ? mean[c] : 0.f;
-        rb_l[at] = (rbar && c < d) ? rbar[c] : 0.f;
+        mu_l[at] = (mean && c < d) ? gld(mean + c) : 0.f;
+        rb_l[at] = (rbar && c < d) ? gld(rbar + c) : 0.f;
     }
     __syncthreads();
     auto lane_major = [&](const float* tab, float* out) {
@@ -240,9 +231,9 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
 #pragma unroll
                 for (int e = 0; e < EPL; e++) dt += x[e] * rbv[e];
                 dt = wave_sum(dt);
-                if (lane == 0 && nrm_out) nrm_out[r] = 1.0f - dt;
+                if (lane == 0 && nrm_out) gst(nrm_out + r, 1.0f - dt);
             }
-            if (lane == 0 && inv_out) inv_out[r] = rden;
+            if (lane == 0 && inv_out) gst(inv_out + r, rden);
             if (vn_out) R::storef(vn_out + (size_t)r * d, d, lane, x);
             if (next || part_out) {  // (the level-0 pass keeps only the column sums: level 1 re-forms its rows)
                 if (half == 0) {
@@ -272,7 +263,7 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
                 s += red[(1 * EPL + e) * SVX_WAVE + l];
                 s += red[(2 * EPL + e) * SVX_WAVE + l];
                 s += red[(3 * EPL + e) * SVX_WAVE + l];
-                part_out[col] = s;
+                gst(part_out + col, s);
             }
         }
     }
