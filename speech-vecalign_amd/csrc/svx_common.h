@@ -52,6 +52,10 @@ __device__ __forceinline__ uint4 gld16(const void* p) {
     const svx_u32x4 v = *(const SVX_GLOBAL(svx_u32x4)*)p;
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ void gst16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const svx_u32x4 v = {a, b, c, d};
+    *(SVX_GLOBAL(svx_u32x4)*)p = v;
+}
 __device__ __forceinline__ float4 gldf4(const float* p) {
     const svx_f32x4 v = *(const SVX_GLOBAL(svx_f32x4)*)p;
     return make_float4(v.x, v.y, v.z, v.w);

@@ -778,7 +778,7 @@ __device__ void sparse_traceback_block(const TbArgs& g, char* smem) {
                 int px, py;
                 if (cor) {
                     const int cc = bb - c0w;
-                    const unsigned char v = (cc >= 0 && cc < g.cw) ? lbp[(size_t)(aa - lo) * g.cw + cc] : g.bpk[(size_t)aa * B + bb];
+                    const unsigned char v = (cc >= 0 && cc < g.cw) ? lbp[(size_t)(aa - lo) * g.cw + cc] : gld(g.bpk + (size_t)aa * B + bb);
                     px = v == 0xFF ? -42 : (v >> 4);
                     py = v == 0xFF ? -42 : (v & 15);
                 } else if (g.chunk > 0) {
@@ -804,7 +804,9 @@ __device__ void sparse_traceback_block(const TbArgs& g, char* smem) {
                     }
                 }
                 if (px < 0 || py < 0 || (px == 0 && py == 0) || px > xx || py > yy) { err = SVX_ERR_TRACEBACK; break; }
-                *reinterpret_cast<int4*>(g.align + 4 * (size_t)(cap - 1 - nw)) = make_int4(xx - px, px, yy - py, py);
+                // (a global store: a flat one would also count against lgkmcnt, and the next step's LDS reads would wait for
+                //  its write acknowledgement -- one memory round trip per step of the walk)
+                gst16(g.align + 4 * (size_t)(cap - 1 - nw), (uint32_t)(xx - px), (uint32_t)px, (uint32_t)(yy - py), (uint32_t)py);
                 xx -= px;
                 yy -= py;
                 nw++;
