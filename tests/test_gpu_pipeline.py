@@ -375,6 +375,26 @@ def test_document_longer_than_the_sort_histogram(orc):
     assert np.abs(got[0]['alignment_scores'] - ref[0]['alignment_scores']).max() < SCORE_TOL
 
 
+def test_mixed_depth_batch_with_long_search_paths(orc):
+    """One svx_align_batch call over pairs of very different pyramid depths: a pair whose level-1 alignment has more
+    rows (~11 000) than the search-path kernel keeps in LDS (9 597: that pair's up-sampling runs on the kernel's
+    one-thread branch), a pair without any pyramid level (L = 0: dense DP at level 0) and two in between.  Every pair
+    against the oracle on its own random stream."""
+    import torch
+    from svx.vecalign import dp_utils
+    shapes = [(11500, 10800), (120, 141), (2300, 1700), (640, 9000)]
+    K, d = 2, 32
+    types = alignment_types(3)
+    hosts = [make_pair(n, m, K, d, 50 + i, deletions=8 if min(n, m) > 200 else 0) for i, (n, m) in enumerate(shapes)]
+    devs = [(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()) for a, b in hosts]
+    res = dp_utils.align_batch(devs, types, 0.2, 6, 300, 20000, 100, rngs=[np.random.RandomState(70 + i) for i in range(len(shapes))])
+    for i, (a, b) in enumerate(hosts):
+        ref = orc.vecalign(a.copy(), b.copy(), types, 0.2, 6, 300, 20000, 100, rng=np.random.RandomState(70 + i))
+        assert len(ref) == len(dp_utils.level_sizes(a.shape[1], b.shape[1], 300))   # (depths 0..L on both sides)
+        assert res[i][0] == ref[0]['final_alignments'], shapes[i]
+        assert np.abs(res[i][1] - ref[0]['alignment_scores']).max() < SCORE_TOL
+
+
 def test_context_follows_current_device():
     """A rank that called torch.cuda.set_device(LOCAL_RANK) must compute on that GPU (seg_align.align under
     torchrun): contexts default to torch's current device.  Needs two visible devices for the non-trivial half."""
