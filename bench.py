@@ -331,6 +331,7 @@ def bench_straight(args):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -518,6 +519,7 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     npairs_local = len(docs)
     total_pairs = npairs_local * args.steps
