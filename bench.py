@@ -282,6 +282,27 @@ def e2e_files(args, dev, K, N, M, d):
 
 
 # ------------------------------------------------------------------------------------------ straight-band workloads
+def init_ranks(torch, local):
+    """-> (device, dist or None, device the timing reductions run on).  One process per GPU over RCCL ("nccl").
+    SVX_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: the ranks share the visible
+    GPUs round-robin and the barrier / MAX / SUM of the timing run over gloo on the host (no RCCL between two
+    ranks of one device); the alignment path itself has no collective either way."""
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    backend = os.environ.get("SVX_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world <= 1:
+        return dev, None, dev
+    import torch.distributed as dist
+    if backend == "gloo":
+        dist.init_process_group("gloo")
+        return dev, dist, torch.device("cpu")
+    dist.init_process_group("nccl", device_id=dev)  # RCCL; used for the timing barrier / max only
+    return dev, dist, dev
+
+
 def bench_straight(args):
     """BASELINE configs[3] (`c4`: N = M = 32768, Sakoe-Chiba band 2048 around the straight diagonal, one pair per
     step) and the dense reading of configs[1] (`dense`: N = M = 4096, every cell of the lattice, a batch of pairs per
@@ -291,13 +312,8 @@ def bench_straight(args):
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
+    dev, dist, rdev = init_ranks(torch, local)
+    local = dev.index
     from svx.vecalign import dp_utils
     K, d = args.overlaps, args.d
     types = alignment_types(K + 1)
@@ -334,7 +350,7 @@ def bench_straight(args):
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     lib.svx_set_profiling(ctx.h, 0)
@@ -443,13 +459,8 @@ def main():
         for c in cpu_children:
             c.kill()
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        dist.init_process_group("nccl", device_id=dev)  # RCCL; used for the timing barrier / max only
+    dev, dist, rdev = init_ranks(torch, local)
+    local = dev.index
 
     from svx import _lib
     from svx.utils.mp_utils import balanced_shards
@@ -468,7 +479,7 @@ def main():
         per_pair = K * (N + M) * d * esz + int(1.6 * K * (N + M) * d * 2) + (8 << 20)
         fit = max(1, int(0.92 * free_b) // per_pair)
         if dist is not None:
-            tf = torch.tensor([fit], device=dev, dtype=torch.int64)
+            tf = torch.tensor([fit], device=rdev, dtype=torch.int64)
             dist.all_reduce(tf, op=dist.ReduceOp.MIN)
             fit = int(tf.item())
         if fit < P:
@@ -524,10 +535,10 @@ def main():
     npairs_local = len(docs)
     total_pairs = npairs_local * args.steps
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        tp = torch.tensor([total_pairs], device=dev, dtype=torch.int64)
+        tp = torch.tensor([total_pairs], device=rdev, dtype=torch.int64)
         dist.all_reduce(tp, op=dist.ReduceOp.SUM)
         total_pairs = int(tp.item())
     lib.svx_set_profiling(ctx.h, 0)
