@@ -333,7 +333,7 @@ def bench_straight(args):
     for _ in range(args.warmup):
         pb.run()
     torch.cuda.synchronize()
-    lib.svx_set_profiling(ctx.h, 1)
+    lib.svx_set_profiling(ctx.h, 2)   # accumulate: events around every stage, read once after the timed steps
     names = ["pyr0", "pyr_aux", "knob_sort", "knob_scores0", "knob", "path", "tiles", "traceback", "setup", "total"]
     ms = {k: 0.0 for k in names}
     if dist is not None:
@@ -342,13 +342,13 @@ def bench_straight(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pb.run()
-        for k in names:
-            ms[k] += lib.svx_stage_ms(ctx.h, k.encode())
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    for k in names:
+        ms[k] = lib.svx_stage_ms(ctx.h, k.encode())
     if dist is not None:
         tt = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -510,7 +510,9 @@ def main():
         pb.run()
     torch.cuda.synchronize()
     if not args.no_profile:
-        lib.svx_set_profiling(ctx.h, 1)
+        # accumulating mode: HIP events around every stage of every timed step, read once after the loop -- the steps
+        # queue behind one another as they do without profiling (mode 1 synchronises after every call to read them)
+        lib.svx_set_profiling(ctx.h, 2)
     stage_names = ["pyr0", "pyr1", "pyrN", "pyr_aux", "knob_sort", "knob_scores0", "knob_scoresN", "knob", "dense_costs", "dense_dp",
                    "path", "band_costs0", "band_costsN", "band_dp0", "band_dpN", "traceback", "setup", "total", "host_plan",
                    "host_launch"]
@@ -523,15 +525,15 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pb.run()
-        if not args.no_profile:  # run() synchronised the stream to read its events
-            for s in stage_names:
-                stage_ms[s] += lib.svx_stage_ms(ctx.h, s.encode())
-                stage_launch[s] += lib.svx_stage_launches(ctx.h, s.encode())
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if not args.no_profile:  # totals over the timed steps
+        for s in stage_names:
+            stage_ms[s] = lib.svx_stage_ms(ctx.h, s.encode())
+            stage_launch[s] = lib.svx_stage_launches(ctx.h, s.encode())
     npairs_local = len(docs)
     total_pairs = npairs_local * args.steps
     if dist is not None:

@@ -282,7 +282,10 @@ int svx_copy_to_host(svx_ctx *ctx, void *dst_host, const void *src_device, int64
  * "pyr0" "pyr1" "pyrN" "pyr_aux" "knob_sort" "knob_scores0" "knob_scoresN" "knob" "dense_costs" "dense_dp" "path"
  * "band_costs0" "band_costsN" "band_dp0" "band_dpN" "traceback" "setup" "total" (0 = level 0, N = deeper levels),
  * "tiles" (the wide-band tile sweep of SVX_SEARCH_STRAIGHT: costs + DP);
- * "host_plan"/"host_launch" are host wall-clock.  -1 if unknown. */
+ * "host_plan"/"host_launch" are host wall-clock.  -1 if unknown.
+ * svx_set_profiling(ctx, 2): accumulate -- the events are recorded as with 1 but a call neither reads them nor waits
+ * for its stream, so calls keep queueing behind one another; svx_stage_ms / svx_stage_launches then return the
+ * totals over all svx_align_batch calls since profiling was set to 2 (the first query synchronises the stream). */
 int svx_set_profiling(svx_ctx *ctx, int on);
 /* Number of internal streams svx_align_batch splits a batch over (1..4, default 1): the serial
  * kernels of one sub-batch overlap the streaming kernels of the others.  Results do not depend on it. */

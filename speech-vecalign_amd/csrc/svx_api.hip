@@ -38,6 +38,10 @@ struct svx_ctx_ext : svx_ctx {
     double ms[S_COUNT];
     int launches[S_COUNT];
     std::vector<StageRec> recs;
+    // profiling mode 2: the event pairs of every call wait here, unread, until a stage time is asked for
+    std::vector<StageRec> pending;
+    double acc_ms[S_COUNT];
+    long long acc_launches[S_COUNT];
     std::vector<SvxPairDev> host;  // descriptors of the last batch (kept alive for the async upload)
     // sub-batches of one svx_align_batch call run on separate streams so that the latency-bound serial
     // kernels (DP, traceback) of one sub-batch overlap the streaming kernels of the other
@@ -75,6 +79,11 @@ struct StageScope {
     }
 };
 
+static void drop_pending(svx_ctx_ext* c) {
+    for (auto& r : c->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    c->pending.clear();
+}
+
 extern "C" {
 
 const char* svx_version(void) { return "svx 0.1 (gfx950)"; }
@@ -111,6 +120,7 @@ int svx_destroy(svx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    drop_pending(X(ctx));
     if (X(ctx)->side_ready) {
         (void)hipStreamDestroy(X(ctx)->side);
         (void)hipEventDestroy(X(ctx)->side_fork);
@@ -146,9 +156,26 @@ int svx_set_streams(svx_ctx* ctx, int n) {
     return SVX_OK;
 }
 
+// mode 2: fold the unread event pairs of the calls so far into the running totals (one stream synchronisation)
+static void fold_pending(svx_ctx_ext* c) {
+    if (c->pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& r : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->acc_ms[r.stage] += ms; }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    c->pending.clear();
+}
+
 int svx_set_profiling(svx_ctx* ctx, int on) {
     if (!ctx) return SVX_ERR_ARG;
+    svx_ctx_ext* c = X(ctx);
+    drop_pending(c);
     ctx->profiling = on;
+    if (on == 2)
+        for (int i = 0; i < S_COUNT; i++) { c->acc_ms[i] = 0.0; c->acc_launches[i] = 0; }
     return SVX_OK;
 }
 
@@ -161,13 +188,20 @@ static int stage_index(const char* name) {
 double svx_stage_ms(svx_ctx* ctx, const char* stage) {
     if (!ctx || !stage) return -1.0;
     int i = stage_index(stage);
-    return i < 0 ? -1.0 : X(ctx)->ms[i];
+    if (i < 0) return -1.0;
+    if (ctx->profiling == 2) {
+        fold_pending(X(ctx));
+        return X(ctx)->acc_ms[i];
+    }
+    return X(ctx)->ms[i];
 }
 
 int svx_stage_launches(svx_ctx* ctx, const char* stage) {
     if (!ctx || !stage) return -1;
     int i = stage_index(stage);
-    return i < 0 ? -1 : X(ctx)->launches[i];
+    if (i < 0) return -1;
+    if (ctx->profiling == 2) return (int)X(ctx)->acc_launches[i];
+    return X(ctx)->launches[i];
 }
 
 }  // extern "C"
@@ -800,7 +834,14 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
     const auto t_done = std::chrono::steady_clock::now();
     cx->ms[S_HOST_PLAN] = std::chrono::duration<double, std::milli>(t_plan - t_enter).count();
     cx->ms[S_HOST_LAUNCH] = std::chrono::duration<double, std::milli>(t_done - t_plan).count();
-    if (ctx->profiling) {
+    if (ctx->profiling == 2) {
+        // accumulate: nothing is read and nothing waits here, the next call can be launched behind this one
+        for (auto& r : cx->recs) cx->pending.push_back(r);
+        cx->recs.clear();
+        for (int i = 0; i < S_COUNT; i++) cx->acc_launches[i] += cx->launches[i];
+        cx->acc_ms[S_HOST_PLAN] += cx->ms[S_HOST_PLAN];
+        cx->acc_ms[S_HOST_LAUNCH] += cx->ms[S_HOST_LAUNCH];
+    } else if (ctx->profiling) {
         SVX_HIP(ctx, hipStreamSynchronize(st));
         for (auto& r : cx->recs) {
             float ms = 0.f;

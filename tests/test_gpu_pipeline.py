@@ -395,6 +395,29 @@ def test_mixed_depth_batch_with_long_search_paths(orc):
         assert np.abs(res[i][1] - ref[0]['alignment_scores']).max() < SCORE_TOL
 
 
+def test_stage_timers_accumulate_without_synchronising():
+    """svx_set_profiling(ctx, 2): stage times and launch counts are totals over the calls since, read back on demand
+    (bench.py's timed loop queues its steps behind one another and reads the HIP events once at the end)."""
+    from svx.vecalign import dp_utils
+    pb = dp_utils.PreparedBatch([make_pair(700, 650, 3, 64, 5)], alignment_types(4), 0.2, 7, 300, 20000, 100,
+                                rngs=[np.random.RandomState(1)])
+    ctx, lib = pb.ctx, pb.ctx.lib
+    pb.run()
+    ctx.sync()
+    lib.svx_set_profiling(ctx.h, 1)
+    pb.run()
+    one = {s: (lib.svx_stage_ms(ctx.h, s.encode()), lib.svx_stage_launches(ctx.h, s.encode())) for s in ("pyr0", "band_dp0", "traceback", "total")}
+    lib.svx_set_profiling(ctx.h, 2)
+    for _ in range(3):
+        pb.run()
+    tot = {s: (lib.svx_stage_ms(ctx.h, s.encode()), lib.svx_stage_launches(ctx.h, s.encode())) for s in one}
+    lib.svx_set_profiling(ctx.h, 0)
+    for s in one:
+        assert tot[s][1] == 3 * one[s][1] and one[s][1] > 0
+        assert 1.5 * one[s][0] < tot[s][0] < 6 * one[s][0]
+    assert lib.svx_stage_ms(ctx.h, b"no such stage") == -1.0
+
+
 def test_context_follows_current_device():
     """A rank that called torch.cuda.set_device(LOCAL_RANK) must compute on that GPU (seg_align.align under
     torchrun): contexts default to torch's current device.  Needs two visible devices for the non-trivial half."""
