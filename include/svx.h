@@ -272,6 +272,19 @@ typedef struct svx_level_view {
     const int32_t *new_b_offset;    /* [path_len + 2]             stack[d]['new_b_offset'] */
     const int32_t *alignments;      /* [n_align][4] rows (x_start, x_len, y_start, y_len) */
     const double *alignment_scores; /* [n_align] (refined levels) */
+    /* the coarsest level of a pyramid (dp_utils.py:465-473), NULL elsewhere: */
+    const float *costs_1to1;        /* [size0][size1]             stack[max_depth]['costs_1to1'] (make_dense_costs) */
+    const int32_t *x_y_tb_diag;     /* stack[max_depth]['x_y_tb'] (dense_dp back-pointers 0 / 1 / 2, 4 at the origin), stored by
+                                     * anti-diagonal: entry (x, y) of the reference's [size0+1][size1+1] array is at
+                                     * [(x + y) * (size0 + 1) + x] */
+    /* levels >= 1: layer 0 of the level's normalised vectors, [size0][d] / [size1][d] float32 = stack[d]['v0'][0], ['v1'][0]
+     * (the other layers of a level are consumed by the pass that forms them and are not kept); NULL at level 0, where the
+     * vectors are the caller's inputs */
+    const float *v0_l0, *v1_l0;
+    /* the sampled 1-1 costs the deletion penalty of this level was estimated from (make_del_knob, dp_utils.py:278-323),
+     * in the order of the caller's knob_idx for this level */
+    const float *knob_scores;       /* [n_knob] */
+    int32_t n_knob, reserved;
 } svx_level_view;
 int svx_debug_level(svx_ctx *ctx, int pair, int level, svx_level_view *out);
 /* Synchronous device -> host copy behind the context's stream (for reading svx_level_view arrays without a tensor library). */

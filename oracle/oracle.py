@@ -270,9 +270,12 @@ def make_del_penalty(e_laser, f_laser, e_norms, f_norms, sample_size, frac, rng)
 
 
 def vecalign(vecs0, vecs1, final_alignment_types, del_percentile_frac, width_over2, max_size_full_dp,
-             costs_sample_size, num_samps_for_norm, norms0=None, norms1=None, rng=None):
+             costs_sample_size, num_samps_for_norm, norms0=None, norms1=None, rng=None, del_penalties=None):
     """dp_utils.py:381-537.  `rng` defaults to numpy's global legacy stream, like the reference;
-    vecs0/vecs1 are normalised IN PLACE, like the reference (dp_utils.py:396-397)."""
+    vecs0/vecs1 are normalised IN PLACE, like the reference (dp_utils.py:396-397).
+    del_penalties (test hook, not in the reference): {depth: value} replaces the estimated deletion penalty of those
+    depths AFTER it was estimated (the random stream is consumed as always; stack[d]['del_penalty_estimated'] keeps
+    the estimate) -- used to separate a percentile knife-edge of the estimate from everything downstream of it."""
     rng = np.random if rng is None else rng
     if width_over2 < 3:
         width_over2 = 3
@@ -307,6 +310,9 @@ def vecalign(vecs0, vecs1, final_alignment_types, del_percentile_frac, width_ove
         st = stack[depth]
         st['del_penalty'], st['knob_scores'] = make_del_penalty(
             st['v0'][0], st['v1'][0], st['n0'][0], st['n1'][0], costs_sample_size, del_percentile_frac, rng)
+        if del_penalties is not None and depth in del_penalties:
+            st['del_penalty_estimated'] = st['del_penalty']
+            st['del_penalty'] = float(del_penalties[depth])
     top = stack[max_depth]
     top['costs_1to1'] = make_dense_costs(top['v0'], top['v1'], top['n0'], top['n1'])
     _, top['x_y_tb'] = dense_dp(top['costs_1to1'], top['del_penalty'])

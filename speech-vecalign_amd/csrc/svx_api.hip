@@ -476,6 +476,16 @@ extern "C" int svx_debug_level(svx_ctx* ctx, int pair, int level, svx_level_view
         out->new_b_offset = Lv.boff_out;
         out->alignment_scores = Lv.scores;
     }
+    if (level == P.L && !P.straight) {  // the dense stage (dp_utils.py:465-473)
+        out->costs_1to1 = P.dcost;
+        out->x_y_tb_diag = P.dbp;
+    }
+    out->knob_scores = Lv.kscore;
+    out->n_knob = Lv.kn;
+    if (level >= 1) {
+        out->v0_l0 = Lv.P[0];
+        out->v1_l0 = Lv.P[1];
+    }
     return SVX_OK;
 }
 

@@ -50,6 +50,8 @@ class LevelView(ctypes.Structure):
         ("n0", c_vp), ("n1", c_vp), ("del_penalty", c_vp), ("searchpath", c_vp), ("a_b_costs", c_vp), ("b_offset", c_vp),
         ("a_b_csum", c_vp), ("a_b_bp", c_vp), ("a_b_xp", c_vp), ("a_b_yp", c_vp), ("new_b_offset", c_vp),
         ("alignments", c_vp), ("alignment_scores", c_vp),
+        ("costs_1to1", c_vp), ("x_y_tb_diag", c_vp), ("v0_l0", c_vp), ("v1_l0", c_vp),
+        ("knob_scores", c_vp), ("n_knob", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 

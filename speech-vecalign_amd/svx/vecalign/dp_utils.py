@@ -299,7 +299,8 @@ class PreparedBatch:
     def level_stack(self, i, depth):
         """The reference's stack[depth] entries (dp_utils.py:412-537) of pair `i` of the last run(), copied from
         the device (svx_debug_level): n0, n1, del_penalty, and for refined levels searchpath, a_b_costs [T][A][B],
-        b_offset, a_b_csum, a_b_xp, a_b_yp, new_b_offset, alignments, alignment_scores."""
+        b_offset, a_b_csum, a_b_xp, a_b_yp, new_b_offset, alignments, alignment_scores; the coarsest level of a
+        pyramid has costs_1to1 and x_y_tb (dp_utils.py:465-473); levels >= 1 have v0_layer0 / v1_layer0 = v0[0] / v1[0]."""
         ctx = self.ctx
         t = ctx.torch
         v = _lib.LevelView()
@@ -320,6 +321,18 @@ class PreparedBatch:
              'del_penalty': float(arr(v.del_penalty, (1,), t.float64)[0])}
         if v.alignments and v.n_align >= 0:
             d['alignments'] = rows_to_alignments(arr(v.alignments, (v.n_align, 4), t.int32))
+        if v.knob_scores and v.n_knob > 0:
+            d['knob_scores'] = arr(v.knob_scores, (v.n_knob,), t.float32)
+        if v.costs_1to1:  # the coarsest level's dense stage (dp_utils.py:465-473)
+            s0, s1 = v.size0, v.size1
+            d['costs_1to1'] = arr(v.costs_1to1, (s0, s1), t.float32)
+            diag = arr(v.x_y_tb_diag, (s0 + s1 + 1, s0 + 1), t.int32)
+            xs, ys = np.meshgrid(np.arange(s0 + 1), np.arange(s1 + 1), indexing='ij')
+            d['x_y_tb'] = np.ascontiguousarray(diag[xs + ys, xs])
+        if v.v0_l0:
+            dim = int(self.prm.d)
+            d['v0_layer0'] = arr(v.v0_l0, (v.size0, dim), t.float32)
+            d['v1_layer0'] = arr(v.v1_l0, (v.size1, dim), t.float32)
         if v.searchpath:
             A, B, T = v.path_len, v.band, v.n_types
             d['searchpath'] = [tuple(p) for p in arr(v.searchpath, (A, 2), t.int32).tolist()]

@@ -13,14 +13,18 @@ do not count as mismatches.
 
 Percentile knife-edges: with very few sampled scores (n*m below costs_sample_size on tiny documents) a step of the
 empirical cdf can coincide with a knot of the percentile map (2/56 == 1/28); which side np.searchsorted falls on is
-then decided by the last bit of the scores, and the deletion penalty jumps by a whole inter-sample gap.  Cases whose
-deletion penalties differ by more than 5e-5 are listed as "penalty knife-edge" with both results, not as mismatches:
-the penalty kernel itself is checked bit for bit against numpy on equal scores in tests/test_gpu_ops.py.  The same
+then decided by the last bit of the scores, and the deletion penalty jumps by a whole inter-sample gap.  The same
 happens whenever sample_size * k / 28 is a whole number (500 samples at percentile 0.5: cdf == 0.5 after exactly 250
 samples): the histogram's bin width is max(scores) / 1000, and a one-ulp change of the largest score -- the size of
-the difference between two summation orders of an fp32 dot product -- moves the rounded cdf across the knot.  Checked
-on the case `--search straight --seed 5` finds (n=248, m=673): numpy's own penalty goes from 1.0040583 to 1.0026617,
-the value the GPU returns, when its largest sample is moved by one ulp.
+the difference between two summation orders of an fp32 dot product -- moves the rounded cdf across the knot.
+A case is counted as a "penalty knife-edge" only when that explanation is CONSTRUCTIVELY verified (knife_edge()):
+  (1) at every level whose penalty differs by more than 5e-5, the GPU's own sampled scores (svx_debug_level ->
+      knob_scores) are within 2e-6 of the oracle's sampled scores, sample by sample, and numpy's DeletionKnob
+      (the oracle's del_penalty_from_scores) applied to the GPU's scores returns the GPU's penalty bit for bit --
+      so the penalty kernel and the sample gather are right and the jump is the reference's own discontinuity;
+  (2) the oracle re-run with the GPU's penalties injected (same random stream) gives the GPU's spans, and scores
+      within 1e-4 (or an exact tie by objective) -- so everything downstream of the estimate is right too.
+Anything else with differing penalties is a MISMATCH.
 
 --search straight runs the same comparison for SVX_SEARCH_STRAIGHT (narrow bands, the tile sweep, and bands that
 cover the whole lattice) against make_sparse_costs / sparse_dp / sparse_traceback on the straight path."""
@@ -34,6 +38,29 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "speech-vecalign_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
+
+
+PEN_TOL, KS_TOL = 5e-5, 2e-6
+
+
+def knife_edge(oracle, gpu_pens, ref_pens, gpu_scores_of, ref_scores_of, frac):
+    """Condition (1) of the module docstring for every level whose penalties differ.  gpu_scores_of(depth) /
+    ref_scores_of(depth) -> float32 sampled scores.  -> (ok, text)"""
+    notes = []
+    for depth, (gp, rp) in enumerate(zip(gpu_pens, ref_pens)):
+        if abs(float(gp) - float(rp)) <= PEN_TOL:
+            continue
+        gs, rsc = np.asarray(gpu_scores_of(depth), np.float32), np.asarray(ref_scores_of(depth), np.float32)
+        if gs.shape != rsc.shape:
+            return False, "level %d: %d sampled scores on the GPU, %d in the oracle" % (depth, gs.size, rsc.size)
+        worst = float(np.abs(gs.astype(np.float64) - rsc.astype(np.float64)).max())
+        if not worst <= KS_TOL:
+            return False, "level %d: sampled scores differ by %.3g" % (depth, worst)
+        want = oracle.del_penalty_from_scores(gs, 0, max(gs), frac)
+        if float(want) != float(gp):
+            return False, "level %d: DeletionKnob(GPU scores) = %.17g, GPU penalty = %.17g" % (depth, float(want), float(gp))
+        notes.append("level %d: scores within %.1e, DeletionKnob(GPU scores) == GPU penalty" % (depth, worst))
+    return True, "; ".join(notes)
 
 
 def run_sweep(cases, seed, batch=8, verbose=True, max_size=900):
@@ -79,8 +106,11 @@ def run_sweep(cases, seed, batch=8, verbose=True, max_size=900):
                 devs.append((torch.from_numpy(v0).cuda(), torch.from_numpy(v1).cuda()))
             hosts.append((v0, v1))
         seeds = [int(rs.randint(1 << 30)) for _ in range(nb)]
+        pb = None
         try:
-            res = dp_utils.align_batch(devs, types, frac, W, max_full, sample, nsamp, rngs=[np.random.RandomState(s) for s in seeds])
+            pb = dp_utils.PreparedBatch(devs, types, frac, W, max_full, sample, nsamp, rngs=[np.random.RandomState(s) for s in seeds])
+            pb.run()
+            res = pb.results()
         except Exception as e:  # an error must be an error on both sides
             res = e
         for i in range(nb):
@@ -107,11 +137,26 @@ def run_sweep(cases, seed, batch=8, verbose=True, max_size=900):
                 if cover and abs(objective(al, sc) - objective(ra, rsc)) < 2e-6 * max(len(al), len(ra)):
                     ties += 1
                     ok = True
-                elif cover and max(abs(float(g) - float(ref[dd]['del_penalty'])) for g, dd in zip(pens, sorted(ref))) > 5e-5:
-                    edges += 1
-                    ok = True
-                    print("penalty knife-edge", dict(n=hosts[i][0].shape[1], m=hosts[i][1].shape[1], sample=sample, frac=frac, store=str(store)),
-                          [float(g) for g in pens], [float(ref[dd]['del_penalty']) for dd in sorted(ref)], flush=True)
+                elif cover and max(abs(float(g) - float(ref[dd]['del_penalty'])) for g, dd in zip(pens, sorted(ref))) > PEN_TOL:
+                    rpens = [float(ref[dd]['del_penalty']) for dd in sorted(ref)]
+                    good, why = knife_edge(oracle, pens, rpens, lambda dd: pb.level_stack(i, dd)['knob_scores'],
+                                           lambda dd: ref[dd]['knob_scores'], frac)
+                    if good:  # (2): the oracle with the GPU's penalties, same random stream
+                        ref2 = oracle.vecalign(hosts[i][0].copy(), hosts[i][1].copy(), types, frac, W, max_full, sample, nsamp,
+                                               rng=np.random.RandomState(seeds[i]), del_penalties={dd: float(g) for dd, g in enumerate(pens)})
+                        pen2 = ref2[0]['del_penalty']
+                        ra2, rs2 = ref2[0]['final_alignments'], ref2[0]['alignment_scores']
+                        obj2 = lambda alg, scores: sum(c * len(x) * len(y) if (x and y) else pen2 * (len(x) + len(y)) for (x, y), c in zip(alg, scores))
+                        same = al == ra2 and (len(sc) == 0 or np.abs(np.asarray(sc) - rs2).max() < 1e-4)
+                        tie2 = abs(obj2(al, sc) - obj2(ra2, rs2)) < 2e-6 * max(len(al), len(ra2))
+                        good = same or tie2
+                        why += "; oracle with the GPU's penalties: " + ("same spans and scores" if same else ("exact tie" if tie2 else "DIFFERENT RESULT"))
+                    if good:
+                        edges += 1
+                        ok = True
+                    print("penalty knife-edge" if good else "penalty differs, NOT a knife-edge:",
+                          dict(n=hosts[i][0].shape[1], m=hosts[i][1].shape[1], sample=sample, frac=frac, store=str(store)),
+                          [float(g) for g in pens], rpens, "|", why, flush=True)
             if not ok:
                 bad += 1
                 print("MISMATCH", dict(K=K, amax=amax, W=W, max_full=max_full, sample=sample, nsamp=nsamp, frac=frac, d=d, store=str(store),
@@ -130,19 +175,20 @@ def run_sweep(cases, seed, batch=8, verbose=True, max_size=900):
     return bad, ties, edges
 
 
-def straight_oracle(orc, v0, v1, types, W, frac, sample, nsamp, seed):
-    """make_sparse_costs + sparse_dp + sparse_traceback on the straight path with depth-0 norms and penalty."""
+def straight_oracle(orc, v0, v1, types, W, frac, sample, nsamp, seed, pen_override=None):
+    """make_sparse_costs + sparse_dp + sparse_traceback on the straight path with depth-0 norms and penalty.
+    -> (alignments, scores, estimated penalty, sampled scores); pen_override replaces the estimate in the DP."""
     N, M = v0.shape[1], v1.shape[1]
     a, b = v0.copy(), v1.copy()
     orc.make_norm1(a)
     orc.make_norm1(b)
     rs = np.random.RandomState(seed)
     n0, n1 = orc.compute_norms(a, b, nsamp, rs), orc.compute_norms(b, a, nsamp, rs)
-    pen, _ = orc.make_del_penalty(a[0], b[0], n0[0], n1[0], sample, frac, rs)
+    pen, ks = orc.make_del_penalty(a[0], b[0], n0[0], n1[0], sample, frac, rs)
     path = orc.search_path([(list(range(N)), list(range(M)))], False, N, M)
     f, bo = orc.make_sparse_costs(a, b, n0, n1, path, types, W)
-    al, sc = orc.sparse_traceback(*orc.sparse_dp(f, bo, types, pen, N, M), N, M)
-    return al, sc, pen
+    al, sc = orc.sparse_traceback(*orc.sparse_dp(f, bo, types, pen if pen_override is None else pen_override, N, M), N, M)
+    return al, sc, pen, ks
 
 
 def run_straight_sweep(cases, seed, batch=6, verbose=True, max_size=500):
@@ -184,8 +230,12 @@ def run_straight_sweep(cases, seed, batch=6, verbose=True, max_size=500):
                 devs.append((torch.from_numpy(v0).cuda(), torch.from_numpy(v1).cuda()))
             hosts.append((v0, v1))
         seeds = [int(rs.randint(1 << 30)) for _ in range(nb)]
+        pb = None
         try:
-            res = dp_utils.align_band_batch(devs, types, frac, W, sample, nsamp, rngs=[np.random.RandomState(s) for s in seeds])
+            pb = dp_utils.PreparedBatch(devs, types, frac, W, 1 << 30, sample, nsamp, rngs=[np.random.RandomState(s) for s in seeds],
+                                        search="straight")
+            pb.run()
+            res = pb.results()
         except Exception as e:
             res = e
         for i in range(nb):
@@ -211,11 +261,22 @@ def run_straight_sweep(cases, seed, batch=6, verbose=True, max_size=500):
                     if cover and abs(objective(al, sc) - objective(ref[0], ref[1])) < 2e-6 * max(len(al), len(ref[0])):
                         ties += 1
                         ok = True
-                    elif cover and abs(float(res[i][2][0]) - float(pen)) > 5e-5:
-                        edges += 1
-                        ok = True
-                        print("penalty knife-edge", dict(n=hosts[i][0].shape[1], m=hosts[i][1].shape[1], sample=sample, frac=frac, store=str(store)),
-                              float(res[i][2][0]), float(pen), flush=True)
+                    elif cover and abs(float(res[i][2][0]) - float(pen)) > PEN_TOL:
+                        gpen = float(res[i][2][0])
+                        good, why = knife_edge(oracle, [gpen], [float(pen)], lambda dd: pb.level_stack(i, 0)['knob_scores'], lambda dd: ref[3], frac)
+                        if good:
+                            ref2 = straight_oracle(oracle, hosts[i][0], hosts[i][1], types, W, frac, sample, nsamp, seeds[i], pen_override=gpen)
+                            obj2 = lambda alg, scores: sum(c * len(x) * len(y) if (x and y) else gpen * (len(x) + len(y)) for (x, y), c in zip(alg, scores))
+                            same = al == ref2[0] and (len(sc) == 0 or np.abs(sc - ref2[1]).max() < 1e-4)
+                            tie2 = abs(obj2(al, sc) - obj2(ref2[0], ref2[1])) < 2e-6 * max(len(al), len(ref2[0]))
+                            good = same or tie2
+                            why += "; oracle with the GPU's penalty: " + ("same spans and scores" if same else ("exact tie" if tie2 else "DIFFERENT RESULT"))
+                        if good:
+                            edges += 1
+                            ok = True
+                        print("penalty knife-edge" if good else "penalty differs, NOT a knife-edge:",
+                              dict(n=hosts[i][0].shape[1], m=hosts[i][1].shape[1], sample=sample, frac=frac, store=str(store)),
+                              gpen, float(pen), "|", why, flush=True)
             if not ok:
                 bad += 1
                 print("MISMATCH straight", dict(K=K, amax=amax, W=W, sample=sample, nsamp=nsamp, frac=frac, d=d, store=str(store),

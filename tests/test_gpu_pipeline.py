@@ -77,6 +77,19 @@ def test_full_stack_vs_oracle(orc):
             assert np.array_equal(np.isfinite(got[d]['a_b_csum']), fin)
             assert np.abs(got[d]['a_b_csum'][fin] - ref[d]['a_b_csum'][fin]).max() < 1e-4 * (1 + ref[d]['a_b_csum'][fin].max())
         assert got[d]['alignments'] == ref[d]['final_alignments' if d == 0 else 'alignments']
+        if d >= 1:  # the level's normalised layer 0 (downsample_vectors, dp_utils.py:362-378)
+            assert np.abs(got[d]['v0_layer0'] - ref[d]['v0'][0]).max() < 2e-6
+            assert np.abs(got[d]['v1_layer0'] - ref[d]['v1'][0]).max() < 2e-6
+    # the coarsest level's dense stage (dp_utils.py:465-473): costs within the matrix-core tolerance; the back-pointer
+    # array bit for bit what dense_dp makes of the SAME float32 costs and penalty, and (nearly) the reference's own
+    top, rtop = got[2], ref[2]
+    assert 'costs_1to1' not in got[0] and 'costs_1to1' not in got[1]
+    assert top['costs_1to1'].shape == rtop['costs_1to1'].shape == (rtop['size0'], rtop['size1'])
+    assert np.abs(top['costs_1to1'] - rtop['costs_1to1']).max() < 4e-6
+    _, tb = orc.dense_dp(top['costs_1to1'], top['del_penalty'])
+    assert top['x_y_tb'].dtype == np.int32 and np.array_equal(top['x_y_tb'], tb)
+    assert (top['x_y_tb'] != rtop['x_y_tb']).mean() < 1e-3   # knife-edge nodes off the optimal path may differ
+    assert orc.dense_traceback(top['x_y_tb']) == rtop['alignments']
 
 
 def test_benchmark_size_vs_oracle(orc):
