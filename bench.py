@@ -150,8 +150,8 @@ STAGE_KERNEL = {
     "knob_scores0": "k_knob_scores<E,NCH,true>", "knob_scoresN": "k_knob_scores<ElemF32,NCH,false>",
     "band_costs0": "k_band_costs (level 0)", "band_costsN": "k_band_costs (levels >= 1)",
     "band_dp0": "k_sparse_dp_fast_batch (level 0)", "band_dpN": "k_sparse_dp_fast_batch (levels >= 1)",
-    "traceback": "k_sparse_traceback_batch", "knob_sort": "k_knob_sort", "knob": "k_del_penalty_batch",
-    "dense_costs": "k_dense_costs_batch", "dense_dp": "k_dense_stage_batch", "path": "k_search_path_batch", "pyr_aux": "k_colmean + k_sample_mean",
+    "traceback": "k_sparse_traceback_batch (levels >= 1)", "traceback0": "k_sparse_traceback_batch (level 0)", "path0": "k_search_path_batch (level 0)", "knob_sort": "k_knob_sort", "knob": "k_del_penalty_batch",
+    "dense_costs": "k_dense_costs_batch", "dense_dp": "k_dense_stage_batch", "path": "k_search_path_batch (levels >= 1)", "pyr_aux": "k_colmean + k_sample_mean",
 }
 
 
@@ -334,7 +334,7 @@ def bench_straight(args):
         pb.run()
     torch.cuda.synchronize()
     lib.svx_set_profiling(ctx.h, 2)   # accumulate: events around every stage, read once after the timed steps
-    names = ["pyr0", "pyr_aux", "knob_sort", "knob_scores0", "knob", "path", "tiles", "traceback", "setup", "total"]
+    names = ["pyr0", "pyr_aux", "knob_sort", "knob_scores0", "knob", "path0", "tiles", "traceback0", "setup", "total"]
     ms = {k: 0.0 for k in names}
     if dist is not None:
         dist.barrier()
@@ -427,7 +427,8 @@ def main():
     ap.add_argument("--e2e_steps", type=int, default=2)
     ap.add_argument("--e2e_files", type=int, default=64, help="document pairs written to disk for the files leg; 0 = skip")
     ap.add_argument("--no_profile", action="store_true")
-    ap.add_argument("--streams", type=int, default=1, help="internal streams a batch is split over (svx_set_streams)")
+    ap.add_argument("--pipeline", type=int, default=1, help="software pipeline over consecutive steps (svx_set_pipeline): the latency-bound "
+                    "refinement chain of one half-batch runs beside the streaming passes of the other; 0 = every step runs start to end on one stream")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -505,16 +506,17 @@ def main():
     ctx = pb.ctx
     lib = ctx.lib
 
-    lib.svx_set_streams(ctx.h, args.streams)
+    ctx.set_pipeline(bool(args.pipeline))
     for _ in range(args.warmup):
         pb.run()
+    pb.flush()
     torch.cuda.synchronize()
     if not args.no_profile:
         # accumulating mode: HIP events around every stage of every timed step, read once after the loop -- the steps
         # queue behind one another as they do without profiling (mode 1 synchronises after every call to read them)
         lib.svx_set_profiling(ctx.h, 2)
     stage_names = ["pyr0", "pyr1", "pyrN", "pyr_aux", "knob_sort", "knob_scores0", "knob_scoresN", "knob", "dense_costs", "dense_dp",
-                   "path", "band_costs0", "band_costsN", "band_dp0", "band_dpN", "traceback", "setup", "total", "host_plan",
+                   "path", "path0", "band_costs0", "band_costsN", "band_dp0", "band_dpN", "traceback", "traceback0", "setup", "total", "host_plan",
                    "host_launch"]
     stage_ms = {s: 0.0 for s in stage_names}
     stage_launch = {s: 0 for s in stage_names}
@@ -525,6 +527,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pb.run()
+    pb.flush()   # (the chain the last step's pipeline held back: inside the timed region)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -556,7 +559,7 @@ def main():
         "metric": "aligned doc-pairs/sec", "value": value, "unit": "doc-pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": wl, "name": args.workload, "pairs_per_step_per_gpu": npairs_local, "streams": args.streams,
+        "config": {"workload": wl, "name": args.workload, "pairs_per_step_per_gpu": npairs_local, "pipeline": int(bool(args.pipeline)),
                    "N": N, "M": M, "d": d, "overlaps": K, "parallelism": "dp%d (pairs sharded, no collective)" % world},
         "dp_cells_per_s": value * cells, "dp_cells_per_pair": cells,
         "hbm_bytes_resident": {"inputs": int(sum(x.numel() * x.element_size() + y.numel() * y.element_size() for x, y in docs)),
@@ -582,21 +585,31 @@ def main():
             dom = max(stages, key=lambda s: stages[s]["ms_per_step"])
             launches = max(1, stage_launch[dom])
             avg_ms = stage_ms[dom] / launches
-            comp_launch = comp_pair * npairs_local          # every launch of a stage processes all pairs of the step
+            # passes over the batch a stage makes per step (one per pyramid level it covers); with the software pipeline a
+            # pass is cut into several launches (half-batches, and slices of them for the two big pyramid passes), so a
+            # launch processes pairs * passes / launches-per-step document pairs
+            L = len(level_sizes(N, M)) - 1
+            passes = {"pyrN": max(1, L - 1), "band_costsN": max(1, L - 1), "band_dpN": max(1, L - 1), "traceback": max(1, L - 1), "path": max(1, L - 1)}.get(dom, 1)
+            pairs_per_launch = npairs_local * passes * args.steps / launches
+            comp_launch = comp_pair * pairs_per_launch
             achieved = comp_launch / (avg_ms * 1e-3) / 1e9
             traffic = traffic_note = None
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
-                same = (tj.get("pairs_per_step") == npairs_local and tj.get("workload") == args.workload and tj.get("dtype") == args.dtype
-                        and (tj.get("N"), tj.get("M"), tj.get("d"), tj.get("overlaps")) == (N, M, d, K))
-                if same and dom in tj.get("hbm_bytes_per_launch", {}):
-                    traffic = tj["hbm_bytes_per_launch"][dom]
-                    traffic_note = tj.get("how")
-            except Exception:
-                pass
+            for tname in ("r03_hbm_traffic.json", "r02_hbm_traffic.json"):   # the newest committed counter run of this configuration
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
+                    same = (tj.get("pairs_per_step") == npairs_local and tj.get("workload") == args.workload and tj.get("dtype") == args.dtype
+                            and (tj.get("N"), tj.get("M"), tj.get("d"), tj.get("overlaps")) == (N, M, d, K))
+                    if same and dom in tj.get("hbm_bytes_per_launch", {}):
+                        # counters are per launch of the run they were taken in; a launch here may cover fewer pairs
+                        per_pair = tj["hbm_bytes_per_launch"][dom] / float(tj.get("pairs_per_launch", {}).get(dom, tj["pairs_per_step"]))
+                        traffic = per_pair * pairs_per_launch
+                        traffic_note = "profiles/%s: %s" % (tname, tj.get("how"))
+                        break
+                except Exception:
+                    pass
             rl = {"bound": "hbm", "kernel": STAGE_KERNEL.get(dom, dom), "stage": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_note,
-                  "avg_launch_ms": avg_ms, "launches_per_step": launches / args.steps,
+                  "avg_launch_ms": avg_ms, "launches_per_step": launches / args.steps, "pairs_per_launch": pairs_per_launch,
                   "algorithmic_bytes_per_launch": comp_launch,
                   "definition": "SURVEY 8(d): K(N+M)d*e bytes per pair x pairs per launch / average launch time",
                   "share_of_step": stage_ms[dom] / stage_ms["total"],

@@ -293,16 +293,27 @@ int svx_copy_to_host(svx_ctx *ctx, void *dst_host, const void *src_device, int64
 /* Device time of the named stage of the last svx_align_batch call, in milliseconds, measured with
  * HIP events on the context's stream when profiling is on (svx_set_profiling); one name per kernel:
  * "pyr0" "pyr1" "pyrN" "pyr_aux" "knob_sort" "knob_scores0" "knob_scoresN" "knob" "dense_costs" "dense_dp" "path"
- * "band_costs0" "band_costsN" "band_dp0" "band_dpN" "traceback" "setup" "total" (0 = level 0, N = deeper levels),
+ * "band_costs0" "band_costsN" "band_dp0" "band_dpN" "path0" "traceback0" "traceback" "setup" "total" (0 = level 0, N = the
+ * deeper levels; "path" and "traceback" without a digit are the deeper levels),
  * "tiles" (the wide-band tile sweep of SVX_SEARCH_STRAIGHT: costs + DP);
  * "host_plan"/"host_launch" are host wall-clock.  -1 if unknown.
  * svx_set_profiling(ctx, 2): accumulate -- the events are recorded as with 1 but a call neither reads them nor waits
  * for its stream, so calls keep queueing behind one another; svx_stage_ms / svx_stage_launches then return the
  * totals over all svx_align_batch calls since profiling was set to 2 (the first query synchronises the stream). */
 int svx_set_profiling(svx_ctx *ctx, int on);
-/* Number of internal streams svx_align_batch splits a batch over (1..4, default 1): the serial
- * kernels of one sub-batch overlap the streaming kernels of the others.  Results do not depend on it. */
-int svx_set_streams(svx_ctx *ctx, int n);
+/* Software pipeline over consecutive svx_align_batch calls (default off).  The path of one document pair is a
+ * streaming front (pyramid, sampled scores: HBM-bound) followed by a refinement chain whose DP / traceback / search-path
+ * kernels are serial per pair and leave the memory system idle.  With the pipeline on, a call cuts its batch into two
+ * halves; every streaming kernel runs on the context's stream in one fixed order, the latency-bound kernels of one
+ * half run beside the streaming kernels of the other on an internal stream, and the refinement chain of the call's
+ * SECOND half is held back to run beside the next call's front.  Contract while it is on: the outputs (and the info
+ * words) of a call are complete, in the order of the context's stream, only after svx_flush() (or svx_synchronize /
+ * svx_debug_level, which flush); inputs and outputs of a call must stay alive until then.  Results do not depend on
+ * the setting.  Wide straight bands (the tile sweep, a persistent kernel over all CUs) always run unpipelined. */
+int svx_set_pipeline(svx_ctx *ctx, int on);
+/* Launch whatever the pipeline still holds back and make the context's stream wait for it (no host synchronisation).
+ * A no-op when nothing is in flight. */
+int svx_flush(svx_ctx *ctx);
 double svx_stage_ms(svx_ctx *ctx, const char *stage);
 /* Number of launches of the named stage in the last batch. */
 int svx_stage_launches(svx_ctx *ctx, const char *stage);

@@ -3,9 +3,12 @@
 // as a fixed sequence of batched kernel launches with no host round trip.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
+#include <functional>
+#include <type_traits>
 #include <vector>
 
 #include "svx_common.h"
@@ -23,15 +26,48 @@ int svx_fail(svx_ctx* ctx, int code, const char* fmt, ...) {
 
 static const char* kStageNames[] = {"pyr0",       "pyrN",     "pyr_aux",      "knob_scoresN", "knob",      "dense_costs",
                                     "dense_dp",   "path",     "band_costs0",  "band_costsN",  "band_dp0",  "band_dpN",
-                                    "traceback",  "setup",    "total",        "host_plan",    "host_launch", "knob_sort", "knob_scores0", "pyr1", "tiles"};
+                                    "traceback",  "setup",    "total",        "host_plan",    "host_launch", "knob_sort", "knob_scores0", "pyr1", "tiles",
+                                    "traceback0", "path0"};
 enum {
     S_PYR0 = 0, S_PYRN, S_PYR_AUX, S_KNOB_SCORES, S_KNOB, S_DENSE_COSTS, S_DENSE_DP, S_PATH, S_BAND_COSTS0, S_BAND_COSTSN,
-    S_BAND_DP0, S_BAND_DPN, S_TRACEBACK, S_SETUP, S_TOTAL, S_HOST_PLAN, S_HOST_LAUNCH, S_KNOB_SORT, S_KNOB_SCORES0, S_PYR1, S_TILES, S_COUNT
+    S_BAND_DP0, S_BAND_DPN, S_TRACEBACK, S_SETUP, S_TOTAL, S_HOST_PLAN, S_HOST_LAUNCH, S_KNOB_SORT, S_KNOB_SCORES0, S_PYR1, S_TILES,
+    S_TRACEBACK0, S_PATH0, S_COUNT
 };
 
 struct StageRec {
     int stage;
     hipEvent_t a, b;
+};
+
+// What the batch driver needs to know about one call beyond the pairs themselves.
+struct BatchParams {
+    SvxTypes tfinal, t11;
+    int W, B, dtype, d, nsamp, n_types;
+    double frac;
+    bool straight, tiles, packable;
+};
+
+// One half of a batch in flight (svx_align_batch, software pipeline): its own scratch arena, descriptors and launch
+// extents.  Without the pipeline slot 0 carries the whole batch.
+struct HalfState {
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    SvxPairDev* pinned = nullptr;      // pinned host copy of the descriptors: the upload never waits for the host
+    size_t pinned_cap = 0;
+    std::vector<SvxPairDev> host;      // host mirror of the descriptors (svx_debug_level)
+    SvxPairDev* dpairs = nullptr;
+    int n_pairs = 0;
+    int maxL = 0, max_ksum = 0, max_kn = 0, max_ds0 = 0, max_ds1 = 0, max_n0 = 0, max_tnd = 0;
+    int max_nblk[SVX_MAX_LEVELS] = {0}, max_A[SVX_MAX_LEVELS] = {0};
+    bool any_L0 = false;
+    size_t o_tickets = 0;
+    // inputs of the launch-order cost model (microseconds are estimated from these; accuracy is not needed)
+    double b_pyr[SVX_MAX_LEVELS] = {0}, b_bc[SVX_MAX_LEVELS] = {0}, b_knobN = 0, b_knob0 = 0, dense_cells = 0;
+    BatchParams bp;
+    bool chain_pending = false;        // streaming front launched, refinement chain not yet
+    bool chain_done_valid = false;
+    hipEvent_t front_done = nullptr, chain_done = nullptr, upload_done = nullptr;
+    bool upload_valid = false;
 };
 
 struct svx_ctx_ext : svx_ctx {
@@ -42,13 +78,17 @@ struct svx_ctx_ext : svx_ctx {
     std::vector<StageRec> pending;
     double acc_ms[S_COUNT];
     long long acc_launches[S_COUNT];
-    std::vector<SvxPairDev> host;  // descriptors of the last batch (kept alive for the async upload)
-    // sub-batches of one svx_align_batch call run on separate streams so that the latency-bound serial
-    // kernels (DP, traceback) of one sub-batch overlap the streaming kernels of the other
-    int n_streams;
-    hipStream_t aux[3];
-    hipEvent_t fork_ev, join_ev[3], stag_ev[3];
-    bool aux_ready;
+    // software pipeline (svx_set_pipeline): a call's batch is cut into two halves; the latency-bound refinement chain
+    // of one half (deletion penalty, coarse DP, per level: search path, band DP, traceback) runs on `chain` beside the
+    // streaming passes of the other half on the context's stream, and the second half's chain is left for the next
+    // call (or svx_flush) to overlap
+    int pipeline;
+    HalfState half[2];
+    int last_split;            // pairs in half[0] at the last call (svx_debug_level)
+    hipStream_t chain;
+    bool chain_ready;
+    std::vector<hipEvent_t> ev_pool;   // events of the launch-order hand-offs, reused round robin
+    size_t ev_next;
     // side stream: small latency-bound kernels that do not depend on the streaming passes (the sample sort)
     hipStream_t side;
     hipEvent_t side_fork, side_join;
@@ -106,10 +146,13 @@ int svx_create(int device_id, svx_ctx** out) {
     c->err[0] = 0;
     c->profiling = 0;
     for (int i = 0; i < S_COUNT; i++) { c->ms[i] = -1.0; c->launches[i] = 0; }
-    c->n_streams = 1;
+    c->pipeline = 0;
+    c->last_split = 0;
+    c->chain = nullptr;
+    c->chain_ready = false;
+    c->ev_next = 0;
     c->last_ntypes = 0;
     c->last_band = 0;
-    c->aux_ready = false;
     c->side_ready = false;
     *out = c;
     return SVX_OK;
@@ -117,20 +160,31 @@ int svx_create(int device_id, svx_ctx** out) {
 
 int svx_destroy(svx_ctx* ctx) {
     if (!ctx) return SVX_OK;
+    svx_ctx_ext* c = X(ctx);
     (void)hipSetDevice(ctx->device);
+    (void)svx_flush(ctx);
     (void)hipStreamSynchronize(ctx->stream);
+    if (c->chain_ready) (void)hipStreamSynchronize(c->chain);
     if (ctx->arena) (void)hipFree(ctx->arena);
-    drop_pending(X(ctx));
-    if (X(ctx)->side_ready) {
-        (void)hipStreamDestroy(X(ctx)->side);
-        (void)hipEventDestroy(X(ctx)->side_fork);
-        (void)hipEventDestroy(X(ctx)->side_join);
+    drop_pending(c);
+    for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    if (c->side_ready) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+        (void)hipEventDestroy(c->side_fork);
+        (void)hipEventDestroy(c->side_join);
     }
-    if (X(ctx)->aux_ready) {
-        for (int i = 0; i < 3; i++) { (void)hipStreamDestroy(X(ctx)->aux[i]); (void)hipEventDestroy(X(ctx)->join_ev[i]); (void)hipEventDestroy(X(ctx)->stag_ev[i]); }
-        (void)hipEventDestroy(X(ctx)->fork_ev);
+    if (c->chain_ready) (void)hipStreamDestroy(c->chain);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    for (int h = 0; h < 2; h++) {
+        HalfState& H = c->half[h];
+        if (H.arena) (void)hipFree(H.arena);
+        if (H.pinned) (void)hipHostFree(H.pinned);
+        if (H.front_done) (void)hipEventDestroy(H.front_done);
+        if (H.chain_done) (void)hipEventDestroy(H.chain_done);
+        if (H.upload_done) (void)hipEventDestroy(H.upload_done);
     }
-    delete X(ctx);
+    delete c;
     return SVX_OK;
 }
 
@@ -142,24 +196,36 @@ int svx_set_stream(svx_ctx* ctx, void* hip_stream) {
 
 int svx_synchronize(svx_ctx* ctx) {
     if (!ctx) return SVX_ERR_ARG;
+    int rc = svx_flush(ctx);  // (the context's stream then waits for everything the pipeline has in flight)
+    if (rc) return rc;
     SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SVX_OK;
 }
 
 const char* svx_last_error(const svx_ctx* ctx) { return ctx ? ctx->err : g_err; }
 
-int64_t svx_scratch_bytes(const svx_ctx* ctx) { return ctx ? (int64_t)ctx->arena_bytes : 0; }
+int64_t svx_scratch_bytes(const svx_ctx* ctx) {
+    if (!ctx) return 0;
+    const svx_ctx_ext* c = static_cast<const svx_ctx_ext*>(ctx);
+    return (int64_t)(ctx->arena_bytes + c->half[0].arena_bytes + c->half[1].arena_bytes);
+}
 
-int svx_set_streams(svx_ctx* ctx, int n) {
-    if (!ctx || n < 1 || n > 4) return SVX_ERR_ARG;
-    X(ctx)->n_streams = n;
+int svx_set_pipeline(svx_ctx* ctx, int on) {
+    if (!ctx || on < 0 || on > 1) return SVX_ERR_ARG;
+    if (X(ctx)->pipeline != on) {
+        int rc = svx_flush(ctx);
+        if (rc) return rc;
+    }
+    X(ctx)->pipeline = on;
     return SVX_OK;
 }
 
 // mode 2: fold the unread event pairs of the calls so far into the running totals (one stream synchronisation)
 static void fold_pending(svx_ctx_ext* c) {
     if (c->pending.empty()) return;
+    (void)svx_flush(c);
     (void)hipStreamSynchronize(c->stream);
+    if (c->side_ready) (void)hipStreamSynchronize(c->side);
     for (auto& r : c->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->acc_ms[r.stage] += ms; }
@@ -399,22 +465,6 @@ int svx_gather_rows(svx_ctx* ctx, const void* table, int64_t n_rows, int d, int 
     return svxl_gather_rows(ctx, table, n_rows, d * (dtype == SVX_F32 ? 4 : 2), dtype, idx, n_out, out);
 }
 
-int svx_num_levels(int n, int m, int max_size_full_dp) {
-    long long s0 = n, s1 = m, lim = (long long)max_size_full_dp * max_size_full_dp;
-    int depth = 0;
-    while (s0 * s1 > lim) {
-        depth++;
-        s0 /= 2;
-        s1 /= 2;
-    }
-    return depth;
-}
-
-int64_t svx_knob_count(int n_l, int m_l, int costs_sample_size) {
-    long long p = (long long)n_l * m_l;
-    return p < costs_sample_size ? p : costs_sample_size;
-}
-
 }  // extern "C"
 
 // ------------------------------------------------------------------------------ fused batch
@@ -448,8 +498,10 @@ extern "C" int svx_copy_to_host(svx_ctx* ctx, void* dst_host, const void* src_de
 extern "C" int svx_debug_level(svx_ctx* ctx, int pair, int level, svx_level_view* out) {
     NEED(ctx, ctx && out, "svx_debug_level: null argument");
     svx_ctx_ext* cx = X(ctx);
-    NEED(ctx, pair >= 0 && pair < (int)cx->host.size(), "svx_debug_level: pair %d of the last batch (%d pairs)", pair, (int)cx->host.size());
-    const SvxPairDev& P = cx->host[pair];
+    const int total = cx->half[0].n_pairs + (cx->last_split > 0 ? cx->half[1].n_pairs : 0);
+    NEED(ctx, pair >= 0 && pair < total, "svx_debug_level: pair %d of the last batch (%d pairs)", pair, total);
+    const bool second = cx->last_split > 0 && pair >= cx->last_split;
+    const SvxPairDev& P = second ? cx->half[1].host[pair - cx->last_split] : cx->half[0].host[pair];
     NEED(ctx, level >= 0 && level <= P.L, "svx_debug_level: level %d (the pair has %d)", level, P.L + 1);
     const SvxLevel& Lv = P.lev[level];
     memset(out, 0, sizeof(*out));
@@ -460,7 +512,8 @@ extern "C" int svx_debug_level(svx_ctx* ctx, int pair, int level, svx_level_view
     out->n0 = Lv.nrm[0]; out->n1 = Lv.nrm[1];
     out->del_penalty = Lv.pen;
     SVX_HIP(ctx, hipSetDevice(ctx->device));
-    SVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = svx_synchronize(ctx);  // (also launches what the pipeline still holds back)
+    if (rc) return rc;
     if (Lv.n_align) SVX_HIP(ctx, hipMemcpy(&out->n_align, Lv.n_align, sizeof(int), hipMemcpyDeviceToHost));
     out->alignments = Lv.align;
     const bool refined = (level < P.L) || (P.L == 0);
@@ -489,48 +542,27 @@ extern "C" int svx_debug_level(svx_ctx* ctx, int pair, int level, svx_level_view
     return SVX_OK;
 }
 
-extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const svx_pair* pairs, int n_pairs) {
-    NEED(ctx, ctx && prm && (pairs || n_pairs == 0), "svx_align_batch: null argument");
-    if (n_pairs <= 0) return SVX_OK;
-    const auto t_enter = std::chrono::steady_clock::now();
-    svx_ctx_ext* cx = X(ctx);
-    SVX_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = check_dim(ctx, prm->d);
-    if (rc) return rc;
-    const int d = prm->d, dtype = prm->dtype;
-    NEED(ctx, dtype == SVX_F32 || dtype == SVX_F16 || dtype == SVX_BF16, "svx_align_batch: unknown dtype %d", dtype);
-    NEED(ctx, prm->max_size_full_dp >= 1, "svx_align_batch: max_size_full_dp must be >= 1");
-    NEED(ctx, prm->costs_sample_size >= 1, "svx_align_batch: costs_sample_size must be >= 1");
-    NEED(ctx, prm->num_samps_for_norm >= 0, "svx_align_batch: num_samps_for_norm must be >= 0");
-    SvxTypes tfinal, t11;
-    if ((rc = make_types(ctx, prm->types, prm->n_types, &tfinal))) return rc;
-    const int32_t one_one[2] = {1, 1};
-    make_types(ctx, one_one, 1, &t11);
-    int W = prm->width_over2 < 3 ? 3 : prm->width_over2;  // dp_utils.py:391-393
-    const int B = 2 * W;
+// ------------------------------------------------------------------------------ plan of one half
+// Level sizes, scratch layout (inside the half's own arena) and launch extents of pairs[0 .. n).
+static int plan_half(svx_ctx* ctx, HalfState& H, const BatchParams& bp, const svx_align_params* prm, const svx_pair* pairs, int n_pairs) {
+    const int d = bp.d;
+    const size_t esz = bp.dtype == SVX_F32 ? 4 : 2;
+    const SvxTypes& tfinal = bp.tfinal;
+    const int B = bp.B;
+    const bool straight = bp.straight, tiles = bp.tiles, packable = bp.packable;
     int mx = 0, my = 0;
     for (int t = 0; t < tfinal.n; t++) { if (tfinal.x[t] > mx) mx = tfinal.x[t]; if (tfinal.y[t] > my) my = tfinal.y[t]; }
-    const bool packable = mx <= 15 && my <= 15;  // back-pointers fit 4 bits each
-    NEED(ctx, prm->search_mode == SVX_SEARCH_COARSE_TO_FINE || prm->search_mode == SVX_SEARCH_STRAIGHT, "svx_align_batch: unknown search_mode %d", prm->search_mode);
-    const bool straight = prm->search_mode == SVX_SEARCH_STRAIGHT;
-    cx->last_ntypes = tfinal.n;
-    cx->last_band = B;
-    // straight search with a band wider than the one-workgroup DP kernel takes: wavefront of tiles (svx_tiles.hip)
-    const bool tiles = straight && B > 64;
-    if (tiles) {
-        NEED(ctx, packable && tfinal.n >= 1 && svxl_band_tiles_ok(tfinal),
-             "wide straight band: the tile kernel takes 1..16 alignment types on <= 12 overlap layers with steps <= 8");
-    }
-
-    // ---- plan: level sizes, scratch layout, launch extents
-    std::vector<SvxPairDev>& host = cx->host;
+    std::vector<SvxPairDev>& host = H.host;
     host.assign(n_pairs, SvxPairDev());
+    H.n_pairs = n_pairs;
+    H.bp = bp;
+    H.maxL = H.max_ksum = H.max_kn = H.max_ds0 = H.max_ds1 = H.max_n0 = H.max_tnd = 0;
+    H.any_L0 = false;
+    H.o_tickets = 0;
+    H.b_knobN = H.b_knob0 = H.dense_cells = 0;
+    for (int l = 0; l < SVX_MAX_LEVELS; l++) { H.max_nblk[l] = H.max_A[l] = 0; H.b_pyr[l] = H.b_bc[l] = 0; }
     Bump bump;
     const size_t o_desc = bump.take((size_t)n_pairs * sizeof(SvxPairDev));
-    size_t o_tickets = 0;  // wide straight bands: ticket table [tile anti-diagonals x pairs + 1] and the ticket counter (below)
-    int maxL = 0, max_ksum = 0, max_kn = 0, max_ds0 = 0, max_ds1 = 0, max_n0 = 0;
-    int max_nblk[SVX_MAX_LEVELS] = {0}, max_A[SVX_MAX_LEVELS] = {0};
-    bool any_L0 = false;
 #define OFF(ptr_field, bytes) set_off(ptr_field, bump, bytes)
     // offsets are stored +1 so that a null pointer stays distinguishable; patched below
     for (int p = 0; p < n_pairs; p++) {
@@ -550,10 +582,10 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         P.norm_override[0] = in.norms0 != nullptr;
         P.norm_override[1] = in.norms1 != nullptr;
         P.status = in.info + 1;
-        if (L > maxL) maxL = L;
-        if (in.n > max_n0) max_n0 = in.n;
-        if (L == 0) any_L0 = true;
-        if (in.k0 + in.k1 > max_ksum) max_ksum = in.k0 + in.k1;
+        if (L > H.maxL) H.maxL = L;
+        if (in.n > H.max_n0) H.max_n0 = in.n;
+        if (L == 0) H.any_L0 = true;
+        if (in.k0 + in.k1 > H.max_ksum) H.max_ksum = in.k0 + in.k1;
         const int S_from[2] = {in.k0 > 0 ? ceil_div(prm->num_samps_for_norm, in.k0) : 0,
                                in.k1 > 0 ? ceil_div(prm->num_samps_for_norm, in.k1) : 0};
         const int32_t* nidx = in.norm_idx;
@@ -564,7 +596,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             for (int s = 0; s < 2; s++) {
                 Lv.n[s] = (s == 0 ? in.n : in.m) >> l;
                 Lv.nblk[s] = ceil_div((Lv.n[s] + 1) / 2, SVX_PYR_SLOTS);
-                if (Lv.nblk[s] > max_nblk[l]) max_nblk[l] = Lv.nblk[s];
+                if (Lv.nblk[s] > H.max_nblk[l]) H.max_nblk[l] = Lv.nblk[s];
             }
             // sampled indices in the reference's draw order: into side 1 (for n0), then into side 0 (for n1)
             for (int s = 1; s >= 0; s--) {
@@ -596,7 +628,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
             Lv.kx = kidx;
             Lv.ky = kidx + kn;
             kidx += 2 * kn;
-            if (Lv.kn > max_kn) max_kn = Lv.kn;
+            if (Lv.kn > H.max_kn) H.max_kn = Lv.kn;
             OFF(Lv.kscore, (size_t)kn * sizeof(float));
             OFF(Lv.korder, (size_t)kn * sizeof(int));
             OFF(Lv.kys, (size_t)kn * sizeof(int));
@@ -609,7 +641,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
                 const int cap = Lv.n[0] + Lv.n[1] + 4;
                 const int T = (l == 0) ? tfinal.n : 1;
                 Lv.path_cap = cap;
-                if (cap > max_A[l]) max_A[l] = cap;
+                if (cap > H.max_A[l]) H.max_A[l] = cap;
                 OFF(Lv.path, (size_t)cap * 2 * sizeof(int));
                 OFF(Lv.path_len, sizeof(int));
                 OFF(Lv.cstart, (size_t)(cap / 16 + 3) * sizeof(int));  // a chunk holds at least 17 path points
@@ -634,11 +666,24 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
                 OFF(Lv.scores, (size_t)rows_cap * sizeof(double));
                 OFF(Lv.n_align, sizeof(int));
             }
+            // launch-order cost model: bytes the streaming passes of this level move
+            const double krows = (double)K[0] * Lv.n[0] + (double)K[1] * Lv.n[1], rows = (double)Lv.n[0] + Lv.n[1];
+            if (l == 0) {
+                H.b_pyr[0] += krows * d * esz;
+                H.b_bc[0] += krows * d * esz;
+                H.b_knob0 += (double)kn * d * esz;
+            } else {
+                if (l == 1) H.b_pyr[1] += ((double)K[0] * in.n + (double)K[1] * in.m) * d * esz + rows * d * 4.0;
+                else H.b_pyr[l] += (krows + rows) * d * 4.0;
+                H.b_pyr[l - 1] += l >= 2 ? krows * d * 4.0 : 0.0;  // (the pair sums the pass below writes)
+                if (l < L) { H.b_bc[l] += rows * d * 4.0; H.b_knobN += (double)kn * d * 4.0; }
+            }
         }
         const SvxLevel& top = P.lev[L];
         if (!straight) {
-            if (top.n[0] > max_ds0) max_ds0 = top.n[0];
-            if (top.n[1] > max_ds1) max_ds1 = top.n[1];
+            if (top.n[0] > H.max_ds0) H.max_ds0 = top.n[0];
+            if (top.n[1] > H.max_ds1) H.max_ds1 = top.n[1];
+            H.dense_cells += (double)top.n[0] * top.n[1];
             OFF(P.dcost, (size_t)top.n[0] * top.n[1] * sizeof(float));
             OFF(P.ddot, (size_t)top.n[0] * top.n[1] * sizeof(float));
             OFF(P.dbp, (size_t)(top.n[0] + top.n[1] + 1) * (top.n[0] + 1) * sizeof(int));  // (anti-diagonal, row) layout
@@ -657,13 +702,32 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         }
     }
 #undef OFF
-    int max_tnd = 0;
     for (int p = 0; p < n_pairs; p++)
-        if (host[p].t_nd > max_tnd) max_tnd = host[p].t_nd;
-    if (tiles) o_tickets = bump.take(((size_t)(max_tnd + 2) * n_pairs + 2) * sizeof(int));
-    if ((rc = arena_reserve(ctx, bump.off))) return rc;
+        if (host[p].t_nd > H.max_tnd) H.max_tnd = host[p].t_nd;
+    if (tiles) H.o_tickets = bump.take(((size_t)(H.max_tnd + 2) * n_pairs + 2) * sizeof(int));
+    // ---- the half's arena (grow-only).  Growing it frees memory that launched work may still use: wait for the device
+    // first (rare: arenas settle after the first calls)
+    if (bump.off > H.arena_bytes) {
+        SVX_HIP(ctx, hipDeviceSynchronize());
+        if (H.arena) SVX_HIP(ctx, hipFree(H.arena));
+        H.arena = nullptr;
+        H.arena_bytes = 0;
+        const size_t want = bump.off + bump.off / 16 + (1 << 20);
+        hipError_t e = hipMalloc(&H.arena, want);
+        if (e != hipSuccess) return svx_fail(ctx, SVX_ERR_NOMEM, "scratch arena: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        H.arena_bytes = want;
+    }
+    const size_t desc_bytes = (size_t)n_pairs * sizeof(SvxPairDev);
+    if (desc_bytes > H.pinned_cap) {
+        SVX_HIP(ctx, hipDeviceSynchronize());  // (an upload out of the old buffer may still be queued)
+        if (H.pinned) SVX_HIP(ctx, hipHostFree(H.pinned));
+        H.pinned = nullptr;
+        H.pinned_cap = 0;
+        SVX_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&H.pinned), desc_bytes + desc_bytes / 8, hipHostMallocDefault));
+        H.pinned_cap = desc_bytes + desc_bytes / 8;
+    }
     // patch offsets (+1) into device pointers
-    char* base = ctx->arena;
+    char* base = H.arena;
     const char* ulo = reinterpret_cast<const char*>(1);
     const char* uhi = reinterpret_cast<const char*>(bump.off + 1);
     auto patch = [&](auto& ptr) {
@@ -690,14 +754,155 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         patch(P.dbp);
         patch(P.t_lo); patch(P.t_cnt); patch(P.t_pref); patch(P.t_flag);
     }
-    SvxPairDev* dpairs = reinterpret_cast<SvxPairDev*>(base + o_desc);
-    hipStream_t st = ctx->stream;
-    const auto t_plan = std::chrono::steady_clock::now();
+    H.dpairs = reinterpret_cast<SvxPairDev*>(base + o_desc);
+    return SVX_OK;
+}
 
-    // ---- run
-    for (int i = 0; i < S_COUNT; i++) { cx->ms[i] = 0.0; cx->launches[i] = 0; }
-    for (auto& r : cx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    cx->recs.clear();
+// ------------------------------------------------------------------------------ launch order
+// The pipeline of one half is a streaming FRONT (pyramid, sampled scores) followed by a refinement CHAIN in which
+// short latency-bound groups LB (deletion penalty, coarse DP; per level: band DP, traceback, next search path) alternate
+// with one streaming kernel S (the level's band costs).  run_interleaved() launches the front of one half and the
+// chain of another in ONE order on two streams: every streaming kernel on the context's stream, where it has the
+// chip's bandwidth to itself, every LB group on the chain stream beside them; an S kernel is placed behind enough
+// front kernels to cover (by the cost model's estimate) the LB group it waits for.
+struct Op {
+    double us;                 // estimated duration
+    int stage;
+    std::function<int()> fn;   // launches on ctx->stream
+};
+
+static int run_op(svx_ctx* ctx, const Op& op, hipStream_t st) {
+    hipStream_t keep = ctx->stream;
+    ctx->stream = st;
+    int rc;
+    if (op.stage < 0) {
+        rc = op.fn();  // (the op times itself)
+    } else {
+        StageScope sc(ctx, op.stage);
+        rc = op.fn();
+    }
+    ctx->stream = keep;
+    return rc;
+}
+
+static int next_event(svx_ctx* ctx, hipEvent_t* out) {
+    svx_ctx_ext* cx = X(ctx);
+    if (cx->ev_pool.size() < 64) {
+        hipEvent_t e;
+        SVX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        cx->ev_pool.push_back(e);
+        *out = e;
+        return SVX_OK;
+    }
+    *out = cx->ev_pool[cx->ev_next++ % cx->ev_pool.size()];  // (64 hand-offs back the event's work is long launched and waited on)
+    return SVX_OK;
+}
+
+// split: the two big passes over the inputs (levels 0 and 1) are launched in `split` slices of the half's pairs, so
+// that the chain running beside this front gets its streaming kernels placed at a finer grain.
+static void front_ops(svx_ctx* ctx, HalfState& H, std::vector<Op>& ops, int split) {
+    svx_ctx_ext* cx = X(ctx);
+    HalfState* h = &H;
+    const BatchParams& bp = H.bp;
+    const int np = H.n_pairs, d = bp.d, dtype = bp.dtype;
+    const double waves = (double)((np + 1023) / 1024);
+    // the counting sort of the sampled (x, y) pairs only needs the descriptors: it runs beside the pyramid (side stream)
+    ops.push_back({0.0, -1, [=]() -> int {
+        hipStream_t main_stream = ctx->stream;
+        SVX_HIP(ctx, hipEventRecord(cx->side_fork, main_stream));
+        SVX_HIP(ctx, hipStreamWaitEvent(cx->side, cx->side_fork, 0));
+        ctx->stream = cx->side;
+        int rc;
+        {
+            StageScope sc(ctx, S_KNOB_SORT);  // (timed on the stream it runs on)
+            rc = svxl_knob_scores(ctx, h->dpairs, np, h->maxL, h->max_kn, h->max_n0, dtype, d, 0);
+        }
+        ctx->stream = main_stream;
+        if (rc) return rc;
+        SVX_HIP(ctx, hipEventRecord(cx->side_join, cx->side));
+        return SVX_OK;
+    }});
+    for (int l = 0; l <= H.maxL; l++) {
+        ops.push_back({l == 0 ? 700.0 * waves : 250.0, S_PYR_AUX, [=]() { return svxl_pyramid_level(ctx, h->dpairs, np, l, dtype, d, h->max_nblk[l], h->max_ksum, 0); }});
+        const int parts = (l <= 1 && split > 1 && np >= 16 * split) ? split : 1;
+        for (int q = 0; q < parts; q++) {
+            const int lo = (int)((long long)np * q / parts), hi = (int)((long long)np * (q + 1) / parts);
+            ops.push_back({H.b_pyr[l] / (l == 0 ? 4.9e6 : 5.3e6) / parts, l == 0 ? S_PYR0 : (l == 1 ? S_PYR1 : S_PYRN),
+                           [=]() { return svxl_pyramid_level(ctx, h->dpairs + lo, hi - lo, l, dtype, d, h->max_nblk[l], h->max_ksum, 1); }});
+        }
+    }
+    if (!bp.straight) {
+        // coarsest level: the dense 1-1 cost matrix, and with it the dot products its sampled scores need
+        ops.push_back({H.dense_cells * 2.7e-5, S_DENSE_COSTS, [=]() -> int {
+            int rc = svxl_dense_costs_batch(ctx, h->dpairs, np, h->max_ds0, h->max_ds1, dtype, d);
+            if (rc) return rc;
+            return svxl_knob_from_dots(ctx, h->dpairs, np, h->max_kn);
+        }});
+    }
+    if (H.maxL >= 1) {
+        ops.push_back({H.b_knobN / 16.5e6, S_KNOB_SCORES, [=]() -> int {
+            SVX_HIP(ctx, hipStreamWaitEvent(ctx->stream, cx->side_join, 0));
+            return svxl_knob_scores(ctx, h->dpairs, np, h->maxL, h->max_kn, h->max_n0, dtype, d, 1);
+        }});
+    }
+    ops.push_back({H.b_knob0 / 8.5e6, S_KNOB_SCORES0, [=]() -> int {
+        SVX_HIP(ctx, hipStreamWaitEvent(ctx->stream, cx->side_join, 0));
+        return svxl_knob_scores(ctx, h->dpairs, np, h->maxL, h->max_kn, h->max_n0, dtype, d, 2);
+    }});
+}
+
+struct Seg {
+    std::vector<Op> lb;   // latency-bound group (chain stream)
+    bool has_s = false;
+    Op s;                 // the streaming kernel that follows it (context's stream)
+};
+
+static void chain_segs(svx_ctx* ctx, HalfState& H, std::vector<Seg>& segs) {
+    HalfState* h = &H;
+    const BatchParams bp = H.bp;
+    const int np = H.n_pairs, d = bp.d, dtype = bp.dtype, W = bp.W, B = bp.B;
+    const double waves = (double)((np + 1023) / 1024);
+    Seg cur;
+    cur.lb.push_back({(np * (H.maxL + 1) * 0.21 < 300.0 ? 300.0 : np * (H.maxL + 1) * 0.21), S_KNOB,
+                      [=]() { return svxl_del_penalty_batch(ctx, h->dpairs, np, h->maxL + 1, bp.frac); }});
+    if (!bp.straight)
+        cur.lb.push_back({(H.max_ds0 + H.max_ds1) * 1.7 * waves, S_DENSE_DP, [=]() { return svxl_dense_stage_batch(ctx, h->dpairs, np, h->max_ds0); }});
+    const int first_depth = H.maxL > 0 ? H.maxL - 1 : 0;
+    for (int depth = first_depth; depth >= 0; depth--) {
+        const SvxTypes ty = depth == 0 ? bp.tfinal : bp.t11;
+        int lim2 = 0, tamax2 = 0;
+        const bool v2 = !bp.tiles && svxl_band2_limits(ty, W, depth, dtype, d, &lim2, &tamax2);  // which band-cost kernel takes this level
+        const int maxA = H.max_A[depth];
+        // (pairs whose source level has more alignment rows than the LDS holds take the kernel's serial path)
+        const int src_rows = (H.maxL > 0 && !H.any_L0) ? maxA / 2 + 8 : maxA;
+        cur.lb.push_back({maxA * 0.08 * waves + 60.0, depth == 0 ? S_PATH0 : S_PATH, [=]() {
+            return svxl_search_path_batch(ctx, h->dpairs, np, depth, maxA, src_rows, v2 ? lim2 : SVX_BC_ROWS - SVX_BC_TB,
+                                          bp.tiles ? 0 : (v2 ? tamax2 : SVX_BC_TAMAX));
+        }});
+        cur.has_s = true;
+        if (bp.tiles) {
+            cur.s = {1.0e4, S_TILES, [=]() {
+                int* tk = reinterpret_cast<int*>(h->arena + h->o_tickets);
+                return svxl_band_tiles_batch(ctx, h->dpairs, np, ty, W, dtype, h->max_tnd, tk, tk + (size_t)h->max_tnd * np + 1);
+            }};
+        } else {
+            cur.s = {H.b_bc[depth] / 4.0e6, depth == 0 ? S_BAND_COSTS0 : S_BAND_COSTSN, [=]() {
+                return v2 ? svxl_band_costs2_batch(ctx, h->dpairs, np, depth, maxA, ty, W, dtype, d)
+                          : svxl_band_costs_batch(ctx, h->dpairs, np, depth, maxA, ty, W, dtype, d);
+            }};
+        }
+        segs.push_back(cur);
+        cur = Seg();
+        if (!bp.tiles)
+            cur.lb.push_back({maxA * (0.21 + 0.054 * (ty.n > 1 ? ty.n : 0)) * waves, depth == 0 ? S_BAND_DP0 : S_BAND_DPN,
+                              [=]() { return svxl_sparse_dp_batch(ctx, h->dpairs, np, depth, ty, B); }});
+        cur.lb.push_back({maxA * 0.27 * waves, depth == 0 ? S_TRACEBACK0 : S_TRACEBACK, [=]() { return svxl_sparse_traceback_batch(ctx, h->dpairs, np, depth, B, maxA, bp.packable ? 1 : 0); }});
+    }
+    segs.push_back(cur);
+}
+
+static int ensure_streams(svx_ctx* ctx) {
+    svx_ctx_ext* cx = X(ctx);
     if (!cx->side_ready) {
         int prio_lo = 0, prio_hi = 0;
         SVX_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // (lowest, highest): the side work only fills gaps
@@ -706,144 +911,190 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         SVX_HIP(ctx, hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming));
         cx->side_ready = true;
     }
-    auto run_stages = [&](SvxPairDev* dp, int np, hipEvent_t streamed_ev) -> int {
-        int rc2;
-        const bool use_side = cx->n_streams <= 1;  // (sub-batch streams already overlap their stages)
-        {
-            // the counting sort of the sampled (x, y) pairs only needs the descriptors: it runs beside the pyramid
-            hipStream_t main_stream = ctx->stream;
-            if (use_side) {
-                SVX_HIP(ctx, hipEventRecord(cx->side_fork, main_stream));
-                SVX_HIP(ctx, hipStreamWaitEvent(cx->side, cx->side_fork, 0));
-                ctx->stream = cx->side;
-            }
-            {
-                StageScope sc(ctx, S_KNOB_SORT);
-                rc2 = svxl_knob_scores(ctx, dp, np, maxL, max_kn, max_n0, dtype, d, 0);
-            }
-            ctx->stream = main_stream;
-            if (rc2) return rc2;
-            if (use_side) SVX_HIP(ctx, hipEventRecord(cx->side_join, cx->side));
-        }
-        for (int l = 0; l <= maxL; l++) {
-            // pyramid: the streaming pass of level l (S_PYR0 / S_PYRN) and its small helpers
-            {
-                StageScope sc(ctx, S_PYR_AUX);
-                if ((rc2 = svxl_pyramid_level(ctx, dp, np, l, dtype, d, max_nblk[l], max_ksum, 0))) return rc2;
-            }
-            StageScope sc(ctx, l == 0 ? S_PYR0 : (l == 1 ? S_PYR1 : S_PYRN));
-            if ((rc2 = svxl_pyramid_level(ctx, dp, np, l, dtype, d, max_nblk[l], max_ksum, 1))) return rc2;
-        }
-        if (!straight) {
-            // coarsest level: the dense 1-1 cost matrix, and with it the dot products its sampled scores need
-            StageScope sc(ctx, S_DENSE_COSTS);
-            if ((rc2 = svxl_dense_costs_batch(ctx, dp, np, max_ds0, max_ds1, dtype, d))) return rc2;
-            if ((rc2 = svxl_knob_from_dots(ctx, dp, np, max_kn))) return rc2;
-        }
-        if (use_side) SVX_HIP(ctx, hipStreamWaitEvent(ctx->stream, cx->side_join, 0));
-        if (maxL >= 1) {
-            StageScope sc(ctx, S_KNOB_SCORES);
-            if ((rc2 = svxl_knob_scores(ctx, dp, np, maxL, max_kn, max_n0, dtype, d, 1))) return rc2;
-        }
-        {
-            StageScope sc(ctx, S_KNOB_SCORES0);
-            if ((rc2 = svxl_knob_scores(ctx, dp, np, maxL, max_kn, max_n0, dtype, d, 2))) return rc2;
-        }
-        // (the next sub-batch starts its streaming passes here: they overlap this one's serial DP stages)
-        if (streamed_ev) SVX_HIP(ctx, hipEventRecord(streamed_ev, ctx->stream));
-        {
-            StageScope sc(ctx, S_KNOB);
-            if ((rc2 = svxl_del_penalty_batch(ctx, dp, np, maxL + 1, prm->del_percentile_frac))) return rc2;
-        }
-        if (!straight) {
-            StageScope sc(ctx, S_DENSE_DP);
-            if ((rc2 = svxl_dense_stage_batch(ctx, dp, np, max_ds0))) return rc2;
-        }
-        const int first_depth = maxL > 0 ? maxL - 1 : 0;
-        for (int depth = first_depth; depth >= 0; depth--) {
-            const SvxTypes& ty = depth == 0 ? tfinal : t11;
-            int lim2 = 0, tamax2 = 0;
-            const bool v2 = !tiles && svxl_band2_limits(ty, W, depth, dtype, d, &lim2, &tamax2);  // which band-cost kernel takes this level
-            {
-                StageScope sc(ctx, S_PATH);
-                // (pairs whose source level has more alignment rows than the LDS holds take the kernel's serial path)
-                const int src_rows = (maxL > 0 && !any_L0) ? max_A[depth] / 2 + 8 : max_A[depth];
-                if ((rc2 = svxl_search_path_batch(ctx, dp, np, depth, max_A[depth], src_rows, v2 ? lim2 : SVX_BC_ROWS - SVX_BC_TB,
-                                                  tiles ? 0 : (v2 ? tamax2 : SVX_BC_TAMAX)))) return rc2;
-            }
-            if (tiles) {
-                StageScope sc(ctx, S_TILES);
-                // (sub-batches on their own streams use disjoint slices of the ticket region)
-                int* tk = reinterpret_cast<int*>(base + o_tickets) + (size_t)max_tnd * (dp - dpairs) + 2 * (dp - dpairs);
-                if ((rc2 = svxl_band_tiles_batch(ctx, dp, np, ty, W, dtype, max_tnd, tk, tk + (size_t)max_tnd * np + 1))) return rc2;
-            } else {
-                {
-                    StageScope sc(ctx, depth == 0 ? S_BAND_COSTS0 : S_BAND_COSTSN);
-                    if (v2) rc2 = svxl_band_costs2_batch(ctx, dp, np, depth, max_A[depth], ty, W, dtype, d);
-                    else rc2 = svxl_band_costs_batch(ctx, dp, np, depth, max_A[depth], ty, W, dtype, d);
-                    if (rc2) return rc2;
-                }
-                {
-                    StageScope sc(ctx, depth == 0 ? S_BAND_DP0 : S_BAND_DPN);
-                    if ((rc2 = svxl_sparse_dp_batch(ctx, dp, np, depth, ty, B))) return rc2;
-                }
-            }
-            {
-                StageScope sc(ctx, S_TRACEBACK);
-                if ((rc2 = svxl_sparse_traceback_batch(ctx, dp, np, depth, B, max_A[depth], packable ? 1 : 0))) return rc2;
-            }
-        }
-        return SVX_OK;
-    };
-    {
-        StageScope total(ctx, S_TOTAL);
+    if (!cx->chain_ready) {
+        int prio_lo = 0, prio_hi = 0;
+        SVX_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        // the chain's few small workgroups should be placed as soon as a streaming workgroup retires
+        SVX_HIP(ctx, hipStreamCreateWithPriority(&cx->chain, hipStreamNonBlocking, prio_hi));
+        cx->chain_ready = true;
+    }
+    for (int h = 0; h < 2; h++) {
+        if (!cx->half[h].front_done) SVX_HIP(ctx, hipEventCreateWithFlags(&cx->half[h].front_done, hipEventDisableTiming));
+        if (!cx->half[h].chain_done) SVX_HIP(ctx, hipEventCreateWithFlags(&cx->half[h].chain_done, hipEventDisableTiming));
+        if (!cx->half[h].upload_done) SVX_HIP(ctx, hipEventCreateWithFlags(&cx->half[h].upload_done, hipEventDisableTiming));
+    }
+    return SVX_OK;
+}
+
+// front: half whose descriptors are uploaded and whose streaming front is launched now (or null);
+// chain: half whose front is on the context's stream already and whose refinement chain is launched now (or null).
+// beside: run the chain's LB groups on the chain stream (else everything goes to the context's stream, in order).
+static int run_interleaved(svx_ctx* ctx, HalfState* front, HalfState* chain, bool beside) {
+    svx_ctx_ext* cx = X(ctx);
+    hipStream_t A = ctx->stream, Bst = beside ? cx->chain : ctx->stream;
+    std::vector<Op> fops;
+    std::vector<Seg> segs;
+    if (front) {
+        // the half's arena and outputs are free once ITS previous chain has finished
+        if (front->chain_done_valid) SVX_HIP(ctx, hipStreamWaitEvent(A, front->chain_done, 0));
         {
             StageScope sc(ctx, S_SETUP);
-            SVX_HIP(ctx, hipMemcpyAsync(dpairs, host.data(), (size_t)n_pairs * sizeof(SvxPairDev), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_init_batch, dim3(n_pairs), dim3(64), 0, st, dpairs);
+            // (the host may be several calls ahead of the device: the previous upload out of this buffer must have left it)
+            if (front->upload_valid) SVX_HIP(ctx, hipEventSynchronize(front->upload_done));
+            memcpy(front->pinned, front->host.data(), (size_t)front->n_pairs * sizeof(SvxPairDev));
+            SVX_HIP(ctx, hipMemcpyAsync(front->dpairs, front->pinned, (size_t)front->n_pairs * sizeof(SvxPairDev), hipMemcpyHostToDevice, A));
+            SVX_HIP(ctx, hipEventRecord(front->upload_done, A));
+            front->upload_valid = true;
+            hipLaunchKernelGGL(k_init_batch, dim3(front->n_pairs), dim3(64), 0, A, front->dpairs);
             SVX_LAUNCH_CHECK(ctx, "k_init_batch");
-            if (prm->num_samps_for_norm == 0) {
+            if (front->bp.nsamp == 0) {
                 // compute_norms returns ones without samples (dp_utils.py:356-357): rbar = 0 -> 1 - 0
-                for (int p = 0; p < n_pairs; p++)
-                    for (int l = 0; l <= host[p].L; l++)
+                for (int p = 0; p < front->n_pairs; p++)
+                    for (int l = 0; l <= front->host[p].L; l++)
                         for (int s = 0; s < 2; s++)
-                            SVX_HIP(ctx, hipMemsetAsync(host[p].lev[l].rbar[s], 0, (size_t)d * sizeof(float), st));
+                            SVX_HIP(ctx, hipMemsetAsync(front->host[p].lev[l].rbar[s], 0, (size_t)front->bp.d * sizeof(float), A));
             }
         }
-        const int S = cx->n_streams < n_pairs ? cx->n_streams : n_pairs;
-        if (S <= 1) {
-            if ((rc = run_stages(dpairs, n_pairs, nullptr))) return rc;
-        } else {
-            if (!cx->aux_ready) {
-                for (int i = 0; i < 3; i++) {
-                    SVX_HIP(ctx, hipStreamCreateWithFlags(&cx->aux[i], hipStreamNonBlocking));
-                    SVX_HIP(ctx, hipEventCreateWithFlags(&cx->join_ev[i], hipEventDisableTiming));
-                    SVX_HIP(ctx, hipEventCreateWithFlags(&cx->stag_ev[i], hipEventDisableTiming));
-                }
-                SVX_HIP(ctx, hipEventCreateWithFlags(&cx->fork_ev, hipEventDisableTiming));
-                cx->aux_ready = true;
-            }
-            SVX_HIP(ctx, hipEventRecord(cx->fork_ev, st));
-            for (int s2 = 0; s2 < S; s2++) {
-                const int lo = (int)((long long)n_pairs * s2 / S), hi = (int)((long long)n_pairs * (s2 + 1) / S);
-                hipStream_t ss = s2 == 0 ? st : cx->aux[s2 - 1];
-                // sub-batch s2 waits until sub-batch s2-1 has finished its streaming front (pyramid + sampled scores)
-                if (s2 > 0) SVX_HIP(ctx, hipStreamWaitEvent(ss, cx->fork_ev, 0));
-                if (s2 > 0) SVX_HIP(ctx, hipStreamWaitEvent(ss, cx->stag_ev[s2 - 1], 0));
-                ctx->stream = ss;
-                rc = run_stages(dpairs + lo, hi - lo, s2 + 1 < S ? cx->stag_ev[s2] : nullptr);
-                ctx->stream = st;
-                if (rc) return rc;
-                if (s2 > 0) {
-                    SVX_HIP(ctx, hipEventRecord(cx->join_ev[s2 - 1], ss));
-                    SVX_HIP(ctx, hipStreamWaitEvent(st, cx->join_ev[s2 - 1], 0));
-                }
-            }
+        static const int split_env = [] { const char* e = getenv("SVX_PIPE_SPLIT"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 8 ? v : 2; }();
+        front_ops(ctx, *front, fops, beside ? split_env : 1);
+    }
+    if (chain) chain_segs(ctx, *chain, segs);
+    int rc;
+    size_t fi = 0;
+    if (chain && beside) SVX_HIP(ctx, hipStreamWaitEvent(Bst, chain->front_done, 0));
+    for (size_t g = 0; g < segs.size(); g++) {
+        double need = 0.0;
+        for (const Op& op : segs[g].lb) {
+            if ((rc = run_op(ctx, op, Bst))) return rc;
+            need += op.us;
+        }
+        hipEvent_t lb_done = nullptr;
+        if (beside) {
+            if ((rc = next_event(ctx, &lb_done))) return rc;
+            SVX_HIP(ctx, hipEventRecord(lb_done, Bst));
+        }
+        if (!segs[g].has_s) break;
+        // cover the group with front kernels before the streaming kernel that waits for it
+        double acc = 0.0;
+        need = need * 1.25 + 50.0;
+        while (beside && fi < fops.size() && acc < need) {
+            if ((rc = run_op(ctx, fops[fi], A))) return rc;
+            acc += fops[fi].us;
+            fi++;
+        }
+        if (beside) SVX_HIP(ctx, hipStreamWaitEvent(A, lb_done, 0));
+        if ((rc = run_op(ctx, segs[g].s, A))) return rc;
+        if (beside) {
+            hipEvent_t s_done;
+            if ((rc = next_event(ctx, &s_done))) return rc;
+            SVX_HIP(ctx, hipEventRecord(s_done, A));
+            SVX_HIP(ctx, hipStreamWaitEvent(Bst, s_done, 0));
         }
     }
+    for (; fi < fops.size(); fi++)
+        if ((rc = run_op(ctx, fops[fi], A))) return rc;
+    if (front) {
+        SVX_HIP(ctx, hipEventRecord(front->front_done, A));
+        front->chain_pending = true;
+    }
+    if (chain) {
+        SVX_HIP(ctx, hipEventRecord(chain->chain_done, Bst));
+        chain->chain_done_valid = true;
+        chain->chain_pending = false;
+    }
+    return SVX_OK;
+}
+
+extern "C" int svx_flush(svx_ctx* ctx) {
+    if (!ctx) return SVX_ERR_ARG;
+    svx_ctx_ext* cx = X(ctx);
+    bool any = false;
+    for (int h = 0; h < 2; h++) any = any || cx->half[h].chain_pending || cx->half[h].chain_done_valid;
+    if (!any) return SVX_OK;
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    for (int h = 0; h < 2; h++)
+        if (cx->half[h].chain_pending && (rc = run_interleaved(ctx, nullptr, &cx->half[h], true))) return rc;
+    // results are complete, in the order of the context's stream, once it has waited for both chains
+    for (int h = 0; h < 2; h++)
+        if (cx->half[h].chain_done_valid) SVX_HIP(ctx, hipStreamWaitEvent(ctx->stream, cx->half[h].chain_done, 0));
+    return SVX_OK;
+}
+
+extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const svx_pair* pairs, int n_pairs) {
+    NEED(ctx, ctx && prm && (pairs || n_pairs == 0), "svx_align_batch: null argument");
+    if (n_pairs <= 0) return SVX_OK;
+    const auto t_enter = std::chrono::steady_clock::now();
+    svx_ctx_ext* cx = X(ctx);
+    SVX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = check_dim(ctx, prm->d);
+    if (rc) return rc;
+    BatchParams bp;
+    bp.d = prm->d;
+    bp.dtype = prm->dtype;
+    NEED(ctx, bp.dtype == SVX_F32 || bp.dtype == SVX_F16 || bp.dtype == SVX_BF16, "svx_align_batch: unknown dtype %d", bp.dtype);
+    NEED(ctx, prm->max_size_full_dp >= 1, "svx_align_batch: max_size_full_dp must be >= 1");
+    NEED(ctx, prm->costs_sample_size >= 1, "svx_align_batch: costs_sample_size must be >= 1");
+    NEED(ctx, prm->num_samps_for_norm >= 0, "svx_align_batch: num_samps_for_norm must be >= 0");
+    if ((rc = make_types(ctx, prm->types, prm->n_types, &bp.tfinal))) return rc;
+    const int32_t one_one[2] = {1, 1};
+    make_types(ctx, one_one, 1, &bp.t11);
+    bp.W = prm->width_over2 < 3 ? 3 : prm->width_over2;  // dp_utils.py:391-393
+    bp.B = 2 * bp.W;
+    bp.nsamp = prm->num_samps_for_norm;
+    bp.frac = prm->del_percentile_frac;
+    bp.n_types = bp.tfinal.n;
+    int mx = 0, my = 0;
+    for (int t = 0; t < bp.tfinal.n; t++) { if (bp.tfinal.x[t] > mx) mx = bp.tfinal.x[t]; if (bp.tfinal.y[t] > my) my = bp.tfinal.y[t]; }
+    bp.packable = mx <= 15 && my <= 15;  // back-pointers fit 4 bits each
+    NEED(ctx, prm->search_mode == SVX_SEARCH_COARSE_TO_FINE || prm->search_mode == SVX_SEARCH_STRAIGHT, "svx_align_batch: unknown search_mode %d", prm->search_mode);
+    bp.straight = prm->search_mode == SVX_SEARCH_STRAIGHT;
+    // straight search with a band wider than the one-workgroup DP kernel takes: wavefront of tiles (svx_tiles.hip)
+    bp.tiles = bp.straight && bp.B > 64;
+    if (bp.tiles) {
+        NEED(ctx, bp.packable && bp.tfinal.n >= 1 && svxl_band_tiles_ok(bp.tfinal),
+             "wide straight band: the tile kernel takes 1..16 alignment types on <= 12 overlap layers with steps <= 8");
+    }
+    if ((rc = ensure_streams(ctx))) return rc;
+    for (int i = 0; i < S_COUNT; i++) { cx->ms[i] = 0.0; cx->launches[i] = 0; }
+    for (auto& r : cx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    cx->recs.clear();
+    // the tile sweep is a persistent kernel over all CUs: nothing runs beside it
+    const bool piped = cx->pipeline != 0 && !bp.tiles && n_pairs >= 2;
+    double plan_ms = 0.0;
+    {
+        StageScope total(ctx, S_TOTAL);
+        if (!piped) {
+            if ((rc = svx_flush(ctx))) return rc;   // (what an earlier pipelined call left behind)
+            HalfState& H = cx->half[0];
+            if ((rc = plan_half(ctx, H, bp, prm, pairs, n_pairs))) return rc;
+            cx->last_split = 0;
+            plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
+            if ((rc = run_interleaved(ctx, &H, nullptr, false))) return rc;
+            if ((rc = run_interleaved(ctx, nullptr, &H, false))) return rc;
+            H.chain_done_valid = false;  // (everything ran on the context's stream: nothing to wait for)
+        } else {
+            const int n0 = (n_pairs + 1) / 2;
+            HalfState &H0 = cx->half[0], &H1 = cx->half[1];
+            if (H0.chain_pending && (rc = run_interleaved(ctx, nullptr, &H0, true))) return rc;  // (cannot happen; kept for safety)
+            auto t0 = std::chrono::steady_clock::now();
+            if ((rc = plan_half(ctx, H0, bp, prm, pairs, n0))) return rc;
+            plan_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            // first half's front beside the chain the previous call left behind
+            if ((rc = run_interleaved(ctx, &H0, H1.chain_pending ? &H1 : nullptr, true))) return rc;
+            t0 = std::chrono::steady_clock::now();
+            if ((rc = plan_half(ctx, H1, bp, prm, pairs + n0, n_pairs - n0))) return rc;
+            plan_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            cx->last_split = n0;
+            // second half's front beside the first half's chain; its own chain waits for the next call or svx_flush
+            if ((rc = run_interleaved(ctx, &H1, &H0, true))) return rc;
+        }
+    }
+    cx->last_ntypes = bp.tfinal.n;
+    cx->last_band = bp.B;
     const auto t_done = std::chrono::steady_clock::now();
-    cx->ms[S_HOST_PLAN] = std::chrono::duration<double, std::milli>(t_plan - t_enter).count();
-    cx->ms[S_HOST_LAUNCH] = std::chrono::duration<double, std::milli>(t_done - t_plan).count();
+    cx->ms[S_HOST_PLAN] = plan_ms;
+    cx->ms[S_HOST_LAUNCH] = std::chrono::duration<double, std::milli>(t_done - t_enter).count() - plan_ms;
     if (ctx->profiling == 2) {
         // accumulate: nothing is read and nothing waits here, the next call can be launched behind this one
         for (auto& r : cx->recs) cx->pending.push_back(r);
@@ -852,10 +1103,11 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         cx->acc_ms[S_HOST_PLAN] += cx->ms[S_HOST_PLAN];
         cx->acc_ms[S_HOST_LAUNCH] += cx->ms[S_HOST_LAUNCH];
     } else if (ctx->profiling) {
-        SVX_HIP(ctx, hipStreamSynchronize(st));
+        if ((rc = svx_synchronize(ctx))) return rc;
+        if (cx->side_ready) SVX_HIP(ctx, hipStreamSynchronize(cx->side));
         for (auto& r : cx->recs) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) cx->ms[r.stage] += ms;  // (stages of sub-batches overlap)
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) cx->ms[r.stage] += ms;
             (void)hipEventDestroy(r.a);
             (void)hipEventDestroy(r.b);
         }

@@ -671,9 +671,15 @@ __host__ __device__ inline size_t tb_win_bytes(int chunk, int B, bool wide) {
 constexpr int TB_COR_CHUNK = 64, TB_COR_W = 320;  // corridor windows: 64 diagonals x 320 columns (drift <= 2 x 64 each way)
 __host__ __device__ inline size_t tb_smem_bytes(int chunk, int B, bool wide) { return 2 * tb_win_bytes(chunk, B, wide); }
 // diagonals per window: a multiple of 16 (so that a window of bytes starts 16-byte aligned) within ~20 KB
-__host__ __device__ inline int tb_chunk(int B, bool wide) {
-    const int c = (int)((20 * 1024) / ((size_t)B * (wide ? 2 : 1) + sizeof(int))) & ~15;
-    return c >= 64 ? c : 0;  // very wide bands walk global memory instead
+__host__ __device__ inline int tb_chunk(int B, bool wide, int win_kb = 20) {
+    const int c = (int)(((size_t)win_kb * 1024) / ((size_t)B * (wide ? 2 : 1) + sizeof(int))) & ~15;
+    if (c >= 64) return c;
+    const int c20 = (int)((20 * 1024) / ((size_t)B * (wide ? 2 : 1) + sizeof(int))) & ~15;
+    return c20 >= 64 ? c20 : 0;  // very wide bands walk global memory instead
+}
+static int tb_win_kb() {
+    static const int v = [] { const char* e = getenv("SVX_TB_WIN_KB"); const int k = e ? atoi(e) : 20; return k >= 2 && k <= 64 ? k : 20; }();
+    return v;
 }
 
 // window j = diagonals [j*chunk, min((j+1)*chunk, Aout)) -> LDS
@@ -1260,9 +1266,13 @@ static int dpf_tpl(int T, int B) {
 
 static int dpf_choose_ch(int T, int B, int maxstep) {
     if (B > 64 || maxstep > 120) return 0;  // transitions are packed into 8-bit fields
-    const int opts[4] = {64, 32, 16, 8};
-    // The sweep is latency-bound, so what matters is how many pairs a CU can host at once: four workgroups
-    // (<= 36 KB of LDS each) if a chunk of >= 16 diagonals allows it, else three.
+    const int opts[5] = {64, 32, 16, 8, 4};
+    // The sweep is latency-bound, so what matters is how many pairs a CU can host at once -- and, when the sweep runs
+    // beside another half-batch's streaming kernels (svx_set_pipeline), that a workgroup fits into the LDS those leave
+    // free: SVX_DP_LDS_KB (default 36: four workgroups per CU) bounds the chunk tables.
+    static const int budget_kb = [] { const char* e = getenv("SVX_DP_LDS_KB"); const int v = e ? atoi(e) : 36; return v >= 6 ? v : 36; }();
+    for (int i = 0; i < 5; i++)
+        if (dpf_smem_bytes(T, B, maxstep + 1, opts[i]) <= (size_t)budget_kb * 1024) return opts[i];
     for (int i = 0; i < 3; i++)
         if (dpf_smem_bytes(T, B, maxstep + 1, opts[i]) <= 36 * 1024) return opts[i];
     for (int i = 0; i < 3; i++)
@@ -1369,7 +1379,7 @@ int svxl_sparse_traceback(svx_ctx* ctx, const double* csum, const int* xp, const
     g.csum = csum; g.xp = xp; g.yp = yp; g.bpk = nullptr; g.boff = boff;
     g.Aout = a_out; g.B = B; g.xs = xs; g.ys = ys;
     g.align = align; g.scores = scores; g.count = count; g.status = nullptr;
-    g.chunk = tb_chunk(B, true);
+    g.chunk = tb_chunk(B, true, tb_win_kb());
     g.cw = 0;
     const size_t smem = g.chunk > 0 ? tb_smem_bytes(g.chunk, B, true) : 0;
     if (smem > 64 * 1024)
@@ -1381,7 +1391,7 @@ int svxl_sparse_traceback(svx_ctx* ctx, const double* csum, const int* xp, const
 
 int svxl_sparse_traceback_batch(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int depth, int B, int max_A, int packed) {
     if (n_pairs <= 0) return SVX_OK;
-    int chunk = tb_chunk(B, !packed), cw = 0;
+    int chunk = tb_chunk(B, !packed, tb_win_kb()), cw = 0;
     size_t smem = chunk > 0 ? tb_smem_bytes(chunk, B, !packed) : 0;
     if (chunk == 0 && packed && B > TB_COR_W && B % 16 == 0) {  // wide band: corridor windows
         chunk = TB_COR_CHUNK;

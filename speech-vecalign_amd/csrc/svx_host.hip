@@ -18,7 +18,9 @@
 #include <unordered_map>
 #include <vector>
 
-#include "svx_common.h"
+#include <stdint.h>
+
+#include "../../include/svx.h"  // (no HIP header: this file also builds with a host compiler, tests/test_host_sanitized.py)
 
 namespace {
 
@@ -129,6 +131,23 @@ bool two_tokens(std::string_view s, std::string_view* t0, std::string_view* t1) 
 }  // namespace
 
 extern "C" {
+
+int svx_num_levels(int n, int m, int max_size_full_dp) {
+    long long s0 = n, s1 = m, lim = (long long)max_size_full_dp * max_size_full_dp;
+    int depth = 0;
+    while (s0 * s1 > lim) {
+        depth++;
+        s0 /= 2;
+        s1 /= 2;
+    }
+    return depth;
+}
+
+int64_t svx_knob_count(int n_l, int m_l, int costs_sample_size) {
+    long long p = (long long)n_l * m_l;
+    return p < costs_sample_size ? p : costs_sample_size;
+}
+
 
 int svx_mt19937_choice(uint32_t* key, int32_t* pos, int64_t n, int64_t size, int32_t* out) {
     if (!key || !pos || !out || n < 1 || n > 0xffffffffLL || size < 0 || *pos < 0 || *pos > MT_N) return SVX_ERR_ARG;
@@ -255,13 +274,13 @@ int svx_candidate_table(const char* seg_path, const char* cat_path, const char* 
 }
 
 int64_t svx_format_alignments(const int32_t* rows, const double* scores, int64_t n, char* out, int64_t cap) {
-    if (!rows || n < 0 || (!out && cap > 0)) return -1;
+    if ((!rows && n > 0) || n < 0 || (!out && cap > 0)) return -1;
     int64_t w = 0;
     auto put = [&](const char* s, int64_t len) {
         if (out && w + len <= cap) memcpy(out + w, s, (size_t)len);
         w += len;
     };
-    char num[64];
+    char num[352];  // "%.6f" of the largest double has 309 digits before the point (found by tests/test_host_sanitized.py: 64 was too few)
     auto list = [&](int start, int len) {
         put("[", 1);
         for (int i = 0; i < len; i++) {

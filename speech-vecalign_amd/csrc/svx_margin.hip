@@ -251,8 +251,8 @@ __device__ __forceinline__ void knn_tile(const char* cur, char* nxt, const uint1
 template <bool BF, typename QE, int RPW, int NW, bool KREG>
 __global__ __launch_bounds__(64 * NW, 1) void k_knn_mean(const typename QE::storage* __restrict__ q, long n,
                                                          const uint16_t* __restrict__ db, long N, int d, int k,
-                                                         float* __restrict__ out, const float* __restrict__ st_in,
-                                                         float* __restrict__ st_out) {
+                                                         float* __restrict__ out, const float* st_in, float* st_out) {
+    // (st_in and st_out are the SAME buffer when svx_knn_topk_merge continues its lists: no __restrict__ on them)
     // Two tile buffers as two LDS objects: the compiler then knows that the ds_reads of one never touch the
     // tile an LDS-DMA is still filling, and does not drain the DMA (s_waitcnt vmcnt(0)) in front of them.
     __shared__ __attribute__((aligned(16))) char tile0[KNN_DT * KNN_RS];

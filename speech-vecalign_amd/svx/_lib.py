@@ -106,7 +106,8 @@ _SIGS = {
     "svx_debug_level": (c_int, [c_vp, c_int, c_int, ctypes.POINTER(LevelView)]),
     "svx_copy_to_host": (c_int, [c_vp, c_vp, c_vp, c_i64]),
     "svx_set_profiling": (c_int, [c_vp, c_int]),
-    "svx_set_streams": (c_int, [c_vp, c_int]),
+    "svx_set_pipeline": (c_int, [c_vp, c_int]),
+    "svx_flush": (c_int, [c_vp]),
     "svx_stage_ms": (c_f64, [c_vp, ctypes.c_char_p]),
     "svx_stage_launches": (c_int, [c_vp, ctypes.c_char_p]),
 }
@@ -170,6 +171,14 @@ class Context:
 
     def sync(self):
         self.check(self.lib.svx_synchronize(self.h))
+
+    def set_pipeline(self, on):
+        """Software pipeline over consecutive svx_align_batch calls (include/svx.h: svx_set_pipeline); while it is on,
+        outputs are complete only after flush() / sync()."""
+        self.check(self.lib.svx_set_pipeline(self.h, 1 if on else 0))
+
+    def flush(self):
+        self.check(self.lib.svx_flush(self.h))
 
     def __del__(self):
         try:

@@ -84,12 +84,14 @@ def compute_sim_with_nonflat_idx(idx_x: FlatIndex, idx_y: FlatIndex, x: np.ndarr
 
 
 def global_margin_scores(x_local, y_local, k: int = 16, margin: str = "ratio", storage: str = "fp16", group=None,
-                         device=None, exchange: str = "ring"):
+                         device=None, exchange: str = "allgather"):
     """Each rank passes the embeddings of ITS alignments; the databases are the union over ranks, the scores come
-    back for the local rows only.  exchange="ring" (default): the normalised fp16 shards travel round the ring of
-    ranks and every rank merges its queries' top-k shard by shard (`ring_shards`, svx_knn_topk_merge) -- two shards
-    of HBM per GPU, transfer overlapped with search.  exchange="allgather": one RCCL all-gather, then a local
-    search of the whole corpus.  Both give the k nearest neighbours over the whole corpus."""
+    back for the local rows only.  exchange="allgather" (default): one RCCL all-gather, then a local search of the
+    whole corpus.  exchange="ring": the normalised fp16 shards travel round the ring of ranks and every rank merges
+    its queries' top-k shard by shard (`ring_shards`, svx_knn_topk_merge) -- two shards of HBM per GPU, transfer
+    overlapped with search; it stays opt-in until a multi-GPU run of tests/test_gpu_margin.py::
+    test_global_margin_over_rccl is on record (the one-GPU box can only run it with a world of one).  Both give the
+    k nearest neighbours over the whole corpus."""
     if exchange not in ("ring", "allgather"):
         raise ValueError(f"exchange {exchange!r}: 'ring' or 'allgather'")
     if margin not in MARGINS:

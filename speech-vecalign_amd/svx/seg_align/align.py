@@ -171,7 +171,11 @@ def align_pairs(pairs: List[VecalignData], args, batch_size: int, io_threads: Op
     ctx = _lib.context()
     dev = ctx.tdev
     nthr = io_threads or max(2, min(32, (os.cpu_count() or 4)))
-    io_pool, out_pool = ThreadPool(nthr), ThreadPool(max(2, nthr // 2))
+    # (the current device is per thread: pool threads that allocate pinned memory must name this rank's GPU, or every
+    #  rank would open a context on GPU 0)
+    dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+    io_pool = ThreadPool(nthr, initializer=torch.cuda.set_device, initargs=(dev_index,))
+    out_pool = ThreadPool(max(2, nthr // 2))
     copy_stream = torch.cuda.Stream(device=dev)
     compute = torch.cuda.current_stream(dev)
     batches = [todo[b0:b0 + batch_size] for b0 in range(0, len(todo), batch_size)]
@@ -195,57 +199,73 @@ def align_pairs(pairs: List[VecalignData], args, batch_size: int, io_threads: Op
         return writes, (pb, held)  # (the pinned result buffers stay alive until the writers are done)
 
     pending_job, pending_writes = None, deque()
-    submit_more()
     bar = my_tqdm(total=len(todo))
-    while ahead:
-        chunk, futs = ahead.popleft()
+    try:
         submit_more()
-        prepared = [f.get() for f in futs]
-        # ---- uploads on the copy stream (pinned -> device), then gather + align on the compute stream
-        with torch.cuda.stream(copy_stream):
-            dev_in = [(torch.from_numpy(st).to(dev, non_blocking=True), torch.from_numpy(tt).to(dev, non_blocking=True),
-                       se.to(dev, non_blocking=True), te.to(dev, non_blocking=True)) for st, tt, se, te in prepared]
-            up = torch.cuda.Event()
-            up.record(copy_stream)
-        compute.wait_event(up)
-        docs = []
-        for (st, tt, se, te), (dst, dtt, dse, dte) in zip(prepared, dev_in):
-            for x in (dst, dtt, dse, dte):
-                x.record_stream(compute)
-            sv, tv = gather_candidates(dse, dst), gather_candidates(dte, dtt)
-            if sv.dtype != tv.dtype:
-                sv, tv = sv.float(), tv.float()
-            docs.append((sv, tv))
-        rngs = None if args.seed is None else [pair_rng(args.seed, p.index) for p in chunk]
-        mode = getattr(args, "mode", "ref")
-        if mode == "ref":
-            w2, search = width_over2, "coarse_to_fine"
-        elif mode == "band":
-            w2, search = max(3, (args.band + 1) // 2), "straight"
-        else:  # dense: the band covers the lattice (width_over2 > max(N, M))
-            w2, search = max(max(int(sv.shape[1]), int(tv.shape[1])) for sv, tv in docs) + 1, "straight"
-        pb = PreparedBatch(docs, types, args.del_percentile_frac, w2, args.max_size_full_dp,
-                           args.costs_sample_size, args.num_samps_for_norm, rngs=rngs, search=search)
-        pb.run()
-        ev = pb.fetch_async()
-        job = (chunk, pb, ev, (prepared, dev_in))
-        # ---- while this batch computes: hand the previous batch to the writers
+        while ahead:
+            chunk, futs = ahead.popleft()
+            submit_more()
+            prepared = [f.get() for f in futs]
+            # ---- uploads on the copy stream (pinned -> device), then gather + align on the compute stream
+            with torch.cuda.stream(copy_stream):
+                dev_in = [(torch.from_numpy(st).to(dev, non_blocking=True), torch.from_numpy(tt).to(dev, non_blocking=True),
+                           se.to(dev, non_blocking=True), te.to(dev, non_blocking=True)) for st, tt, se, te in prepared]
+                up = torch.cuda.Event()
+                up.record(copy_stream)
+            compute.wait_event(up)
+            docs = []
+            for (st, tt, se, te), (dst, dtt, dse, dte) in zip(prepared, dev_in):
+                for x in (dst, dtt, dse, dte):
+                    x.record_stream(compute)
+                sv, tv = gather_candidates(dse, dst), gather_candidates(dte, dtt)
+                if sv.dtype != tv.dtype:
+                    sv, tv = sv.float(), tv.float()
+                docs.append((sv, tv))
+            rngs = None if args.seed is None else [pair_rng(args.seed, p.index) for p in chunk]
+            mode = getattr(args, "mode", "ref")
+            if mode == "ref":
+                w2, search = width_over2, "coarse_to_fine"
+            elif mode == "band":
+                w2, search = max(3, (args.band + 1) // 2), "straight"
+            else:  # dense: the band covers the lattice (width_over2 > max(N, M))
+                w2, search = max(max(int(sv.shape[1]), int(tv.shape[1])) for sv, tv in docs) + 1, "straight"
+            pb = PreparedBatch(docs, types, args.del_percentile_frac, w2, args.max_size_full_dp,
+                               args.costs_sample_size, args.num_samps_for_norm, rngs=rngs, search=search)
+            pb.run()
+            ev = pb.fetch_async()
+            job = (chunk, pb, ev, (prepared, dev_in))
+            # ---- while this batch computes: hand the previous batch to the writers
+            if pending_job is not None:
+                pending_writes.append(finish(pending_job))
+                bar.update(len(pending_job[0]))
+            pending_job = job
+            while len(pending_writes) > 1:
+                for w in pending_writes.popleft()[0]:
+                    w.get()
         if pending_job is not None:
             pending_writes.append(finish(pending_job))
             bar.update(len(pending_job[0]))
-        pending_job = job
-        while len(pending_writes) > 1:
-            for w in pending_writes.popleft()[0]:
+        for writes, _ in pending_writes:
+            for w in writes:
                 w.get()
-    if pending_job is not None:
-        pending_writes.append(finish(pending_job))
-        bar.update(len(pending_job[0]))
-    for writes, _ in pending_writes:
-        for w in writes:
-            w.get()
-    bar.close()
-    io_pool.close()
-    out_pool.close()
+    except BaseException:
+        # a failed pair must not leave threads behind: drop the reads still queued, let the writes already handed
+        # over finish (their files are complete or absent: write-then-rename), then re-raise
+        io_pool.terminate()
+        for writes, _ in pending_writes:
+            for w in writes:
+                try:
+                    w.get(timeout=120)
+                except Exception:
+                    pass
+        out_pool.terminate()
+        raise
+    finally:
+        bar.close()
+        io_pool.close()
+        out_pool.close()
+        io_pool.join()
+        out_pool.join()
     if stats is not None:
         stats["pairs"] = len(todo)
         stats["io_threads"] = nthr

@@ -18,6 +18,7 @@ Differences from the reference, by design:
 """
 import ctypes
 import logging
+from collections import OrderedDict
 from math import ceil
 
 import numpy as np
@@ -270,10 +271,16 @@ class PreparedBatch:
         ctx.use_current_stream()
         ctx.check(ctx.lib.svx_align_batch(ctx.h, ctypes.byref(self.prm), self.cpairs, len(self.vecs)))
 
+    def flush(self):
+        """With the context's pipeline on (Context.set_pipeline): launch what run() held back and order it in front of
+        whatever follows on the current stream."""
+        self.ctx.flush()
+
     def fetch_async(self):
         """Queue the device -> pinned-host copies of the outputs behind run() on the current stream and return
         an event that fires when they have landed (the host pipeline formats batch i while batch i+1 computes)."""
         t = self.ctx.torch
+        self.ctx.flush()  # (a no-op unless the pipeline is on)
         self.h_out = tuple(t.empty(x.shape, dtype=x.dtype, pin_memory=True) for x in (self.info, self.align, self.scores, self.del_pen))
         for h, d in zip(self.h_out, (self.info, self.align, self.scores, self.del_pen)):
             h.copy_(d, non_blocking=True)
@@ -381,8 +388,17 @@ def vecalign(vecs0, vecs1, final_alignment_types, del_percentile_frac, width_ove
     a_b_xp, a_b_yp, new_b_offset, alignments: PreparedBatch.level_stack), copied back from the device."""
     pb = PreparedBatch([(vecs0, vecs1)], final_alignment_types, del_percentile_frac, width_over2, max_size_full_dp,
                        costs_sample_size, num_samps_for_norm, norms=[(norms0, norms1)])
-    pb.run()
-    alignments, scores, pens = pb.results()[0]
+    timed = logger.isEnabledFor(logging.INFO)
+    if timed:
+        pb.ctx.check(pb.ctx.lib.svx_set_profiling(pb.ctx.h, 1))
+    try:
+        pb.run()
+        alignments, scores, pens = pb.results()[0]
+        if timed:
+            log_phase_times(pb.ctx)
+    finally:
+        if timed:
+            pb.ctx.lib.svx_set_profiling(pb.ctx.h, 0)
     sizes = level_sizes(vecs0.shape[1], vecs1.shape[1], max_size_full_dp)
     stack = {}
     for depth, (s0, s1) in enumerate(sizes):
@@ -396,6 +412,33 @@ def vecalign(vecs0, vecs1, final_alignment_types, del_percentile_frac, width_ove
         make_norm1(vecs0)
         make_norm1(vecs1)
     return stack
+
+
+# the reference's phases (dp_utils.py:400,415-419,446,457,462-475,518-528) and the device stages that do their work;
+# the fused pyramid pass of level 0 also produces that level's row norms and n0 / n1, so it is the "normalize" phase
+PHASES = (('Downsample embeddings', ('pyr1', 'pyrN', 'pyr_aux')),
+          ('Normalize embeddings', ('pyr0',)),
+          ('Compute deletion penalties', ('knob_sort', 'knob_scores0', 'knob_scoresN', 'knob')),
+          ('Full DP make features', ('dense_costs',)),
+          ('Full DP', ('dense_dp',)),
+          ('Upsample DP compute costs', ('path', 'band_costsN')),
+          ('Upsample DP', ('band_dpN', 'traceback')),
+          ('Final DP compute costs', ('path0', 'band_costs0', 'tiles')),
+          ('Final DP', ('band_dp0', 'traceback0')))
+
+
+def log_phase_times(ctx):
+    """The reference's closing timing log (dp_utils.py:530-535: 'key took ....... 0.1234s' at INFO on logger
+    'vecalign', phases above 5e-5 s only), from the device stage timers of the last call (svx_stage_ms; needs
+    svx_set_profiling(1) around the call)."""
+    runtimes = OrderedDict()
+    for key, stages in PHASES:
+        runtimes[key] = sum(max(0.0, float(ctx.lib.svx_stage_ms(ctx.h, s.encode()))) for s in stages) * 1e-3
+    max_key_str_len = max(len(key) for key in runtimes)
+    for key in runtimes:
+        if runtimes[key] > 5e-5:
+            logger.info(key + ' took ' + '.' * (max_key_str_len + 5 - len(key)) + ('%.4fs' % runtimes[key]).rjust(7))
+    return runtimes
 
 
 # ------------------------------------------------------------------------------------- per-function mirrors

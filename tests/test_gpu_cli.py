@@ -76,6 +76,30 @@ def test_seeded_runs_are_batch_invariant(tmp_path):
     assert os.path.getmtime(os.path.join(str(tmp_path / "out1"), "en-de", "doc0_en-doc0_de.txt")) == stamp
 
 
+def test_cli_shards_partition_the_pair_list(tmp_path):
+    """--rank / --n_shard (mp_utils.py:7-16 semantics; here cost-balanced): two shards run one after the other on one GPU
+    write disjoint sets of files whose union is byte-identical to the unsharded run -- the per-pair sampling streams
+    derive from (seed, position in the validated list), not from the position inside a shard."""
+    root = str(tmp_path / "data")
+    build_tree(root, copies=5)
+    names = [f"doc{c}_en-doc{c}_de.txt" for c in range(5)]
+    whole = str(tmp_path / "whole")
+    run_cli(root, whole, ["--fp16_embed", "--seed", "3", "--n_shard", "1", "--rank", "0"])
+    ref = {n: open(os.path.join(whole, "en-de", n), "rb").read() for n in names}
+    assert len(set(ref.values())) > 1          # different pairs draw different samples: the scores differ
+    seen = {}
+    for rank in (0, 1):
+        out = str(tmp_path / ("shard%d" % rank))
+        run_cli(root, out, ["--fp16_embed", "--seed", "3", "--n_shard", "2", "--rank", str(rank), "--batch_size", "2"])
+        for n in sorted(os.listdir(os.path.join(out, "en-de"))):
+            assert n not in seen, "pair aligned by both shards"
+            seen[n] = open(os.path.join(out, "en-de", n), "rb").read()
+    assert seen == ref
+    with pytest.raises(AssertionError):        # the reference's get_shard_range check, same message
+        from svx.utils.mp_utils import get_shard_range
+        get_shard_range(5, 2, 2)
+
+
 def test_cli_band_and_dense_modes(tmp_path):
     """--mode band / dense (additive flags): on the trimmed example the band around the straight diagonal and the whole
     lattice both contain the optimum the coarse-to-fine search finds, so all three modes print the same spans."""

@@ -208,6 +208,25 @@ def test_knn_topk_merge_shard_by_shard(orc, t, storage, k, n, shards):
     assert np.abs(got - orc.knn_mean_sim(q, stored(orc, db, storage), k, storage)).max() < TOL[storage]
 
 
+def test_global_margin_ring_exchange_world_of_one(orc, t):
+    """global_margin_scores(exchange="ring") on one process: the ring has a single shard, so the path through
+    ring_shards -> FlatIndex.merge_topk (svx_knn_topk_merge) -> svx_margin_scores runs on the device without any
+    communication, and must agree with the all-gather path and with the oracle."""
+    from svx.postprocess.score_align import global_margin_scores
+    n, d, k = 900, 256, 16
+    x, y = unit_rows(n, d, 31), unit_rows(n, d, 32)
+    xd, yd = t.from_numpy(x).cuda(), t.from_numpy(y).cuda()
+    ring = global_margin_scores(xd, yd, k=k, exchange="ring").cpu().numpy()
+    gathered = global_margin_scores(xd, yd, k=k, exchange="allgather").cpu().numpy()
+    default = global_margin_scores(xd, yd, k=k).cpu().numpy()
+    assert np.array_equal(default, gathered)
+    assert np.abs(ring - gathered).max() < 2e-7
+    want = orc.margin_scores(x, y, stored(orc, x, "fp16"), stored(orc, y, "fp16"), k, "ratio", "fp16")
+    assert np.abs(ring - want).max() < 1e-5
+    with pytest.raises(ValueError):
+        global_margin_scores(xd[:5], yd[:5], k=k, exchange="ring")   # fewer rows than k
+
+
 def test_global_margin_over_rccl():
     """BASELINE configs[4]'s exchange on real devices: one process per GPU, every rank scoring its own shard against the
     union of all ranks' unit rows -- once with the shards travelling round the ring (ring_shards + svx_knn_topk_merge,

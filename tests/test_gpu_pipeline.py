@@ -136,23 +136,80 @@ def test_batch_invariance_and_idempotence():
         assert xs == list(range(shapes[i][0])) and ys == list(range(shapes[i][1]))
 
 
-def test_stream_count_does_not_change_results():
-    """svx_set_streams only changes how sub-batches overlap in time."""
+def test_pipeline_does_not_change_results():
+    """svx_set_pipeline only changes WHEN kernels run: consecutive calls -- same batch again, a different batch, an
+    odd number of pairs, a single pair -- give bit-identical outputs with the software pipeline on and off, and the
+    stack of a pair in the held-back half reads back the same."""
     from svx import _lib
     from svx.vecalign import dp_utils
     types = alignment_types(4)
     docs = [make_pair(500 + 37 * i, 520 - 11 * i, 3, 64, 60 + i) for i in range(5)]
+    more = [make_pair(900 - 50 * i, 700 + 90 * i, 3, 64, 80 + i) for i in range(4)]
     ctx = _lib.context()
-    outs = []
+
+    def sequence():
+        outs = []
+        mk = lambda ds, s0: dp_utils.PreparedBatch(ds, types, 0.2, 7, 300, 20000, 100, rngs=[np.random.RandomState(s0 + i) for i in range(len(ds))])
+        a, b, c = mk(docs, 0), mk(more, 100), mk(docs[:1], 200)
+        for pb in (a, a, b, c, a):     # every run() overlaps the chain the one before it held back
+            pb.run()
+        a.flush()
+        for pb in (a, b, c):
+            outs.append(pb.results())
+        outs.append(a.level_stack(4, 0)['a_b_csum'])   # a pair of the second (held-back) half
+        return outs
     try:
-        for ns in (1, 2, 4):
-            ctx.lib.svx_set_streams(ctx.h, ns)
-            outs.append(dp_utils.align_batch(docs, types, 0.2, 7, 300, 20000, 100, rngs=[np.random.RandomState(i) for i in range(5)]))
+        ctx.set_pipeline(False)
+        plain = sequence()
+        ctx.set_pipeline(True)
+        piped = sequence()
     finally:
-        ctx.lib.svx_set_streams(ctx.h, 1)
-    for o in outs[1:]:
-        for a, b in zip(outs[0], o):
-            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        ctx.set_pipeline(False)
+    for o, q in zip(plain[:3], piped[:3]):
+        assert len(o) == len(q)
+        for x, y in zip(o, q):
+            assert x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
+    assert np.array_equal(plain[3], piped[3])
+
+
+def test_phase_timing_log_like_the_reference():
+    """The reference closes vecalign() with one INFO line per phase on logger 'vecalign' (dp_utils.py:530-535); here the
+    same lines are written from the device stage timers when that logger is enabled for INFO, and cost nothing otherwise."""
+    import logging
+    import re
+    from svx.vecalign import dp_utils
+    v0, v1 = make_pair(1300, 1200, 4, 64, 9)
+    types = alignment_types(5)
+    lg = logging.getLogger('vecalign')
+    seen = []
+
+    class Grab(logging.Handler):
+        def emit(self, record):
+            seen.append(record.getMessage())
+    h, old = Grab(), lg.level
+    lg.addHandler(h)
+    try:
+        lg.setLevel(logging.INFO)
+        np.random.seed(2)
+        timed = dp_utils.vecalign(v0, v1, types, 0.2, 7, 300, 20000, 100)
+        lines = [m for m in seen if ' took ' in m]
+        lg.setLevel(logging.WARNING)
+        del seen[:]
+        np.random.seed(2)
+        quiet = dp_utils.vecalign(v0, v1, types, 0.2, 7, 300, 20000, 100)
+        assert not seen
+    finally:
+        lg.setLevel(old)
+        lg.removeHandler(h)
+    keys = [k for k, _ in dp_utils.PHASES]
+    pat = re.compile(r'^(%s) took \.+ *\d+\.\d{4}s$' % '|'.join(re.escape(k) for k in keys))
+    assert lines and all(pat.match(m) for m in lines), lines
+    got = [pat.match(m).group(1) for m in lines]
+    assert got == [k for k in keys if k in got]                      # the reference's order
+    for must in ('Compute deletion penalties', 'Upsample DP', 'Final DP'):   # (like the reference, phases under 50 us are not logged)
+        assert must in got, lines
+    assert len({len(m) for m in lines}) == 1                         # right-aligned like the reference's
+    assert timed[0]['final_alignments'] == quiet[0]['final_alignments'] and np.array_equal(timed[0]['alignment_scores'], quiet[0]['alignment_scores'])
 
 
 def test_norm_overrides_and_global_stream(orc):
