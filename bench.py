@@ -314,7 +314,9 @@ def bench_straight(args):
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     dev, dist, rdev = init_ranks(torch, local)
     local = dev.index
+    from svx import _lib
     from svx.vecalign import dp_utils
+    _lib.context(local).set_pipeline(False)   # (the tile sweep never pipelines; narrow straight bands are not benchmarked here)
     K, d = args.overlaps, args.d
     types = alignment_types(K + 1)
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
@@ -383,10 +385,9 @@ def bench_straight(args):
                         "avg_launch_ms": tile_ms, "algorithmic_flops_per_launch": flops * P,
                         "note": "the sweep is bound by the serial chain of tile anti-diagonals (%d of them) and the float64 DP inside a tile, "
                                 "not by the matrix cores" % ((N // 32 + 1) + (M // 32 + 1) - 1)}}
-    if rank == 0:
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    del pb, docs
+    torch.cuda.empty_cache()
+    return out if rank == 0 else None
 
 
 # ------------------------------------------------------------------------------------------ main
@@ -427,15 +428,54 @@ def main():
     ap.add_argument("--e2e_steps", type=int, default=2)
     ap.add_argument("--e2e_files", type=int, default=64, help="document pairs written to disk for the files leg; 0 = skip")
     ap.add_argument("--no_profile", action="store_true")
+    ap.add_argument("--extra_workloads", type=int, default=1, help="default c2 run on one GPU: also time bounded legs of c3, c4 (1 / 4 / 8 pairs "
+                    "per step) and the dense mode, reported under `workloads`; 0 = skip")
     ap.add_argument("--pipeline", type=int, default=1, help="software pipeline over consecutive steps (svx_set_pipeline): the latency-bound "
                     "refinement chain of one half-batch runs beside the streaming passes of the other; 0 = every step runs start to end on one stream")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
-    if args.workload in ("c4", "dense"):
-        return bench_straight(args)
+    out = bench_straight(args) if args.workload in ("c4", "dense") else bench_ctf(args)
+    if out is not None:
+        if args.extra_workloads and args.workload == "c2" and int(os.environ.get("WORLD_SIZE", 1)) == 1:
+            out["workloads"] = extra_workloads(args)
+        print(json.dumps(out))
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
+
+def extra_workloads(args):
+    """The other BASELINE configurations and the dense reading of configs[1], each as a bounded leg of the default run
+    (same process, after the c2 legs have released their memory): value + roofline object per leg."""
+    import copy
+    legs = {}
+
+    def leg(name, **kw):
+        a = copy.copy(args)
+        a.cpu_pairs, a.cpu_procs, a.e2e_pairs, a.e2e_files, a.extra_workloads = 0, 0, 0, 0, 0
+        for k, v in kw.items():
+            setattr(a, k, v)
+        t = time.perf_counter()
+        try:
+            r = bench_straight(a) if a.workload in ("c4", "dense") else bench_ctf(a)
+            keep = ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "seconds_per_pair", "dp_cells_per_s",
+                    "stage_ms_per_step", "alignments_cover_both_documents")
+            legs[name] = {k: r[k] for k in keep if k in r}
+            legs[name]["leg_seconds"] = time.perf_counter() - t
+        except Exception as e:  # never lose the headline line to a side leg
+            legs[name] = {"error": repr(e)}
+    leg("c3", workload="c3", pairs=1024, steps=2, warmup=1)
+    leg("c4_1pair", workload="c4", pairs=1, steps=2, warmup=1)
+    leg("c4_4pairs", workload="c4", pairs=4, steps=2, warmup=1)
+    leg("c4_8pairs", workload="c4", pairs=8, steps=1, warmup=1)
+    leg("dense", workload="dense", pairs=64, steps=1, warmup=1)
+    return legs
+
+
+def bench_ctf(args):
+    """Workloads c2 / c3: the reference's coarse-to-fine search.  -> the result dict on rank 0, None elsewhere."""
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -547,6 +587,7 @@ def main():
         dist.all_reduce(tp, op=dist.ReduceOp.SUM)
         total_pairs = int(tp.item())
     lib.svx_set_profiling(ctx.h, 0)
+    ctx.set_pipeline(False)   # (the legs below -- CPU parity sample, end-to-end, other workloads -- start from the default state)
     res = pb.results()
 
     value = total_pairs / elapsed
@@ -685,9 +726,8 @@ def main():
                 out.setdefault("cpu_baseline", {})["all_cores"] = {"error": repr(e)}
                 for c in cpu_children:
                     c.kill()
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == "__main__":
