@@ -8,6 +8,7 @@
 
 #include <chrono>
 #include <functional>
+#include <memory>
 #include <type_traits>
 #include <vector>
 
@@ -787,30 +788,39 @@ static int run_op(svx_ctx* ctx, const Op& op, hipStream_t st) {
 
 static int next_event(svx_ctx* ctx, hipEvent_t* out) {
     svx_ctx_ext* cx = X(ctx);
-    if (cx->ev_pool.size() < 64) {
+    if (cx->ev_pool.size() < 256) {
         hipEvent_t e;
         SVX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         cx->ev_pool.push_back(e);
         *out = e;
         return SVX_OK;
     }
-    *out = cx->ev_pool[cx->ev_next++ % cx->ev_pool.size()];  // (64 hand-offs back the event's work is long launched and waited on)
+    *out = cx->ev_pool[cx->ev_next++ % cx->ev_pool.size()];  // (a wait refers to the record it was queued behind: re-recording an event later does not disturb it)
     return SVX_OK;
 }
 
-// split: the two big passes over the inputs (levels 0 and 1) are launched in `split` slices of the half's pairs, so
-// that the chain running beside this front gets its streaming kernels placed at a finer grain.
+// split: every pyramid pass is launched in `split` slices of the half's pairs.  The chain running beside this front
+// then gets its streaming kernels placed at a finer grain, and the small latency-bound helpers of a level (column means
+// from the block partials, mean of the sampled rows) run on the side stream for slice q while slice q+1 is still in the
+// pass of the level above -- off the critical path of the context's stream.
 static void front_ops(svx_ctx* ctx, HalfState& H, std::vector<Op>& ops, int split) {
     svx_ctx_ext* cx = X(ctx);
     HalfState* h = &H;
     const BatchParams& bp = H.bp;
     const int np = H.n_pairs, d = bp.d, dtype = bp.dtype;
     const double waves = (double)((np + 1023) / 1024);
-    // the counting sort of the sampled (x, y) pairs only needs the descriptors: it runs beside the pyramid (side stream)
+    const int parts = (split > 1 && np >= 16 * split) ? split : 1;
+    struct Evs { hipEvent_t pass[SVX_MAX_LEVELS][8]; };
+    auto evs = std::make_shared<Evs>();
+    // marks the start of this front on the context's stream: the side stream's work must not run ahead of it
     ops.push_back({0.0, -1, [=]() -> int {
-        hipStream_t main_stream = ctx->stream;
-        SVX_HIP(ctx, hipEventRecord(cx->side_fork, main_stream));
+        SVX_HIP(ctx, hipEventRecord(cx->side_fork, ctx->stream));
         SVX_HIP(ctx, hipStreamWaitEvent(cx->side, cx->side_fork, 0));
+        return SVX_OK;
+    }});
+    auto sort_op = [=]() -> int {
+        // the counting sort of the sampled (x, y) pairs only needs the descriptors: side stream, beside the pyramid
+        hipStream_t main_stream = ctx->stream;
         ctx->stream = cx->side;
         int rc;
         {
@@ -821,15 +831,41 @@ static void front_ops(svx_ctx* ctx, HalfState& H, std::vector<Op>& ops, int spli
         if (rc) return rc;
         SVX_HIP(ctx, hipEventRecord(cx->side_join, cx->side));
         return SVX_OK;
-    }});
+    };
+    if (parts == 1) ops.push_back({0.0, -1, sort_op});
     for (int l = 0; l <= H.maxL; l++) {
-        ops.push_back({l == 0 ? 700.0 * waves : 250.0, S_PYR_AUX, [=]() { return svxl_pyramid_level(ctx, h->dpairs, np, l, dtype, d, h->max_nblk[l], h->max_ksum, 0); }});
-        const int parts = (l <= 1 && split > 1 && np >= 16 * split) ? split : 1;
         for (int q = 0; q < parts; q++) {
             const int lo = (int)((long long)np * q / parts), hi = (int)((long long)np * (q + 1) / parts);
-            ops.push_back({H.b_pyr[l] / (l == 0 ? 4.9e6 : 5.3e6) / parts, l == 0 ? S_PYR0 : (l == 1 ? S_PYR1 : S_PYRN),
-                           [=]() { return svxl_pyramid_level(ctx, h->dpairs + lo, hi - lo, l, dtype, d, h->max_nblk[l], h->max_ksum, 1); }});
+            const double aux_us = (l == 0 ? 700.0 * waves : 250.0) / parts;
+            if (parts == 1) {
+                ops.push_back({aux_us, S_PYR_AUX, [=]() { return svxl_pyramid_level(ctx, h->dpairs, np, l, dtype, d, h->max_nblk[l], h->max_ksum, 0); }});
+                ops.push_back({H.b_pyr[l] / (l == 0 ? 4.9e6 : 5.3e6), l == 0 ? S_PYR0 : (l == 1 ? S_PYR1 : S_PYRN),
+                               [=]() { return svxl_pyramid_level(ctx, h->dpairs, np, l, dtype, d, h->max_nblk[l], h->max_ksum, 1); }});
+                continue;
+            }
+            ops.push_back({H.b_pyr[l] / (l == 0 ? 4.9e6 : 5.3e6) / parts, l == 0 ? S_PYR0 : (l == 1 ? S_PYR1 : S_PYRN), [=]() -> int {
+                hipStream_t main_stream = ctx->stream;
+                // the slice's helpers: side stream, behind the slice's pass of the level above
+                if (l > 0) SVX_HIP(ctx, hipStreamWaitEvent(cx->side, evs->pass[l - 1][q], 0));
+                ctx->stream = cx->side;
+                int rc;
+                {
+                    StageScope sc(ctx, S_PYR_AUX);
+                    rc = svxl_pyramid_level(ctx, h->dpairs + lo, hi - lo, l, dtype, d, h->max_nblk[l], h->max_ksum, 0);
+                }
+                ctx->stream = main_stream;
+                if (rc) return rc;
+                hipEvent_t aux_done;
+                if ((rc = next_event(ctx, &aux_done))) return rc;
+                SVX_HIP(ctx, hipEventRecord(aux_done, cx->side));
+                SVX_HIP(ctx, hipStreamWaitEvent(main_stream, aux_done, 0));
+                if ((rc = svxl_pyramid_level(ctx, h->dpairs + lo, hi - lo, l, dtype, d, h->max_nblk[l], h->max_ksum, 1))) return rc;
+                if ((rc = next_event(ctx, &evs->pass[l][q]))) return rc;
+                SVX_HIP(ctx, hipEventRecord(evs->pass[l][q], main_stream));
+                return SVX_OK;
+            }});
         }
+        if (parts > 1 && l == 0) ops.push_back({0.0, -1, sort_op});   // (behind the level-0 helpers on the side stream)
     }
     if (!bp.straight) {
         // coarsest level: the dense 1-1 cost matrix, and with it the dot products its sampled scores need

@@ -8,7 +8,9 @@
 #define SVX_WAVE 64
 
 // Row-pair slots handled by one k_pyramid workgroup (4 waves x 8 slots).
+#ifndef SVX_PYR_SLOTS
 #define SVX_PYR_SLOTS 32
+#endif
 // Band-cost tiling: path points per chunk, band cells per chunk, rows staged per side.
 #define SVX_BC_TA 32
 // The fused pipeline cuts the path into chunks of up to SVX_BC_TAMAX points whose extent on either side still
@@ -50,6 +52,10 @@ template <typename T>
 __device__ __forceinline__ void gst(T* p, T v) { *(SVX_GLOBAL(T)*)p = v; }
 __device__ __forceinline__ uint4 gld16(const void* p) {
     const svx_u32x4 v = *(const SVX_GLOBAL(svx_u32x4)*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint4 gld16_nt(const void* p) {  // streaming read: the line is not kept for a later pass
+    const svx_u32x4 v = __builtin_nontemporal_load((const SVX_GLOBAL(svx_u32x4)*)p);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void gst16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {

@@ -52,11 +52,14 @@ struct Row {
             }
         }
     }
+    // FULL: the row fills the lane map exactly (d == NCH * 64 * VEC), no lane is ever out of range -- without the test
+    // the compiler needs no exec-masked branch (and no register copies to merge its two sides) around every piece
+    template <bool FULL = false>
     __device__ static __forceinline__ void storef(float* v, int d, int lane, const float* x) {
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             int col = (c * SVX_WAVE + lane) * VEC;
-            if (col < d) {
+            if (FULL || col < d) {
 #pragma unroll
                 for (int q = 0; q < VEC / 4; q++) {
                     gstf4(v + col + 4 * q, x[c * VEC + 4 * q + 0], x[c * VEC + 4 * q + 1], x[c * VEC + 4 * q + 2], x[c * VEC + 4 * q + 3]);
@@ -65,11 +68,12 @@ struct Row {
         }
     }
     // streaming store: written once, read by a later kernel after tens of GB of other traffic
+    template <bool FULL = false>
     __device__ static __forceinline__ void storef_nt(float* v, int d, int lane, const float* x) {
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             int col = (c * SVX_WAVE + lane) * VEC;
-            if (col < d) {
+            if (FULL || col < d) {
 #pragma unroll
                 for (int q = 0; q < VEC / 4; q++) {
                     gstf4_nt(v + col + 4 * q, x[c * VEC + 4 * q + 0], x[c * VEC + 4 * q + 1], x[c * VEC + 4 * q + 2], x[c * VEC + 4 * q + 3]);
@@ -112,19 +116,21 @@ struct RawRow {
     float ia, ib;
 };
 
-template <typename E, int NCH, bool PAIR>
+// NT: non-temporal loads (the row is not read again before the cache has turned over)
+template <typename E, int NCH, bool PAIR, bool NT = false, bool FULL = false>
 __device__ __forceinline__ void fetch_raw(const typename E::storage* rows, const float* inv0, int r, int d, int lane,
                                           RawRow<E, NCH, PAIR>& out) {
     constexpr int VEC = E::VEC;
+    auto ld = [](const void* p) { return NT ? gld16_nt(p) : gld16(p); };
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
         const int col = (c * SVX_WAVE + lane) * VEC;
-        const bool in = col < d;
+        const bool in = FULL || col < d;
         if (PAIR) {
-            out.p[c] = in ? gld16(rows + (size_t)(2 * r) * d + col) : make_uint4(0, 0, 0, 0);
-            out.p[NCH + c] = in ? gld16(rows + (size_t)(2 * r + 1) * d + col) : make_uint4(0, 0, 0, 0);
+            out.p[c] = in ? ld(rows + (size_t)(2 * r) * d + col) : make_uint4(0, 0, 0, 0);
+            out.p[NCH + c] = in ? ld(rows + (size_t)(2 * r + 1) * d + col) : make_uint4(0, 0, 0, 0);
         } else {
-            out.p[c] = in ? gld16(rows + (size_t)r * d + col) : make_uint4(0, 0, 0, 0);
+            out.p[c] = in ? ld(rows + (size_t)r * d + col) : make_uint4(0, 0, 0, 0);
         }
     }
     if (PAIR) {
@@ -158,7 +164,7 @@ __device__ __forceinline__ void decode_raw(const RawRow<E, NCH, PAIR>& in, float
 
 // PAIR: `rows` are the level-0 rows and this block works on level 1, whose rows are formed on the fly
 // (pair_row arithmetic) instead of being read back from memory.
-template <typename E, int NCH, bool PAIR = false>
+template <typename E, int NCH, bool PAIR = false, bool NT = false, bool FULL = false>
 __device__ void pyr_block(const typename E::storage* rows, int n, int d, const float* mean, const float* rbar,
                           float* inv_out, float* nrm_out, float* vn_out, float* next, float* part_out, int blk,
                           float* lds, const float* inv0 = nullptr) {
@@ -199,7 +205,7 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
     RawRow<E, NCH, PAIR> ring[DEPTH];
 #pragma unroll
     for (int s = 0; s < DEPTH; s++)
-        if (r0 + s < r1) fetch_raw<E, NCH, PAIR>(rows, inv0, r0 + s, d, lane, ring[s]);
+        if (r0 + s < r1) fetch_raw<E, NCH, PAIR, NT, FULL>(rows, inv0, r0 + s, d, lane, ring[s]);
 #pragma unroll 1
     for (int rb = r0; rb < r1; rb += DEPTH) {
 #pragma unroll
@@ -209,7 +215,7 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
             const int jp = r >> 1, half = r & 1;
             float x[EPL];
             decode_raw<E, NCH, PAIR>(ring[s], x);
-            if (r + DEPTH < r1) fetch_raw<E, NCH, PAIR>(rows, inv0, r + DEPTH, d, lane, ring[s]);
+            if (r + DEPTH < r1) fetch_raw<E, NCH, PAIR, NT, FULL>(rows, inv0, r + DEPTH, d, lane, ring[s]);
             if (mean) {
                 float mu[EPL];
                 lane_major(mu_l, mu);
@@ -224,7 +230,12 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
             const float rden = 1.0f / den;  // one division per row; the elements are scaled by the reciprocal
 #pragma unroll
             for (int e = 0; e < EPL; e++) x[e] = x[e] * rden;
+#ifdef SVX_EXP_NODOT
+            if (lane == 0 && nrm_out) gst(nrm_out + r, 1.0f);   // (timing experiment: the dot product with rbar and its reduction left out)
+            if (false) {
+#else
             if (rbar) {
+#endif
                 float rbv[EPL];
                 lane_major(rb_l, rbv);
                 float dt = 0.f;
@@ -234,7 +245,7 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
                 if (lane == 0 && nrm_out) gst(nrm_out + r, 1.0f - dt);
             }
             if (lane == 0 && inv_out) gst(inv_out + r, rden);
-            if (vn_out) R::storef(vn_out + (size_t)r * d, d, lane, x);
+            if (vn_out) R::template storef<FULL>(vn_out + (size_t)r * d, d, lane, x);
             if (next || part_out) {  // (the level-0 pass keeps only the column sums: level 1 re-forms its rows)
                 if (half == 0) {
 #pragma unroll
@@ -245,7 +256,7 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
                         xs[e] = xs[e] + x[e];
                         cs[e] += xs[e];
                     }
-                    if (next) R::storef_nt(next + (size_t)jp * d, d, lane, xs);
+                    if (next) R::template storef_nt<FULL>(next + (size_t)jp * d, d, lane, xs);
                 }
             }
         }
@@ -264,6 +275,137 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
                 s += red[(2 * EPL + e) * SVX_WAVE + l];
                 s += red[(3 * EPL + e) * SVX_WAVE + l];
                 gst(part_out + col, s);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- level 0, lean
+// The level-0 pass keeps nothing of a row but three scalars -- 1/(||u|| + 1e-5), 1 - <unit row, rbar> -- and its
+// share of the column sums of the unit rows' pair sums; the generic block above spends ~200 vector instructions per
+// 2 KB row on it, which (not the memory system) bounds it.  This block does the same arithmetic for the values that
+// are kept (sum of squares as one fma chain + butterfly, the two products and one sum of every pair-sum element, no
+// contraction) with about half the instructions:
+//   * rows are taken two at a time (no copy of the first row of a pair into a second set of registers);
+//   * <unit row, rbar> is evaluated as rden * <raw row, rbar>, so that both reductions of a row start together;
+//   * the four reductions of a row pair (two sums of squares, two dot products) share ONE butterfly: two
+//     v_permlane32_swap + add fold the wave's halves of (a, b), one v_permlane16_swap + add puts the four values
+//     into the four 16-lane rows of a single register, four DPP steps finish all of them at once.
+template <typename E, int NCH, bool FULL = false>
+__device__ void pyr0_block(const typename E::storage* rows, int n, int d, const float* rbar, float* inv_out, float* nrm_out,
+                           float* part_out, int blk, float* lds) {
+    using R = Row<E, NCH>;
+    constexpr int EPL = R::EPL;
+    constexpr int DP = EPL * SVX_WAVE;
+    constexpr int DEPTH = E::VEC == 8 ? 4 : 2;   // rows in flight per wave (an even number: rows travel in pairs)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* rb_l = lds;            // rbar, lane-major (see pyr_block)
+    float* red = lds + 2 * DP;
+    if (rbar) {
+        for (int c = threadIdx.x; c < DP; c += blockDim.x) {
+            const int ch = c / (SVX_WAVE * E::VEC), l = (c / E::VEC) % SVX_WAVE, i = c % E::VEC;
+            const int e = ch * E::VEC + i;
+            rb_l[((e >> 2) * SVX_WAVE + l) * 4 + (e & 3)] = c < d ? gld(rbar + c) : 0.f;
+        }
+    }
+    const int slot0 = blk * SVX_PYR_SLOTS + w * (SVX_PYR_SLOTS / 4);
+    const int r0 = 2 * slot0;
+    int r1 = r0 + 2 * (SVX_PYR_SLOTS / 4);
+    r1 = r1 < n ? r1 : n;
+    RawRow<E, NCH, false> ring[DEPTH];
+#pragma unroll
+    for (int s = 0; s < DEPTH; s++)
+        if (r0 + s < r1) fetch_raw<E, NCH, false, false, FULL>(rows, nullptr, r0 + s, d, lane, ring[s]);
+    __syncthreads();   // rbar is staged (the rows' loads are already in flight)
+    float cs[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) cs[e] = 0.f;
+    const int npairs_rows = 2 * (n / 2);   // rows that have a partner (an odd last row only gets its scalars)
+#pragma unroll 1
+    for (int rb = r0; rb < r1; rb += DEPTH) {
+#pragma unroll
+        for (int s = 0; s < DEPTH; s += 2) {
+            const int ra = rb + s;
+            if (ra >= r1) break;  // wave-uniform
+            const bool has_b = ra + 1 < r1;
+            float xa[EPL], xb[EPL];
+            decode_raw<E, NCH, false>(ring[s], xa);
+            decode_raw<E, NCH, false>(ring[s + 1], xb);
+            if (!has_b) {
+#pragma unroll
+                for (int e = 0; e < EPL; e++) xb[e] = 0.f;
+            }
+            if (ra + DEPTH < r1) fetch_raw<E, NCH, false, false, FULL>(rows, nullptr, ra + DEPTH, d, lane, ring[s]);
+            if (ra + 1 + DEPTH < r1) fetch_raw<E, NCH, false, false, FULL>(rows, nullptr, ra + 1 + DEPTH, d, lane, ring[s + 1]);
+            float ssa = 0.f, ssb = 0.f, da = 0.f, db = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; e++) { ssa += xa[e] * xa[e]; ssb += xb[e] * xb[e]; }
+#ifndef SVX_EXP_P0
+#define SVX_EXP_P0 0   // timing experiments only (bit 0: no dot with rbar, bit 1: no column sums, bit 2: no butterfly / sqrt)
+#endif
+            if (rbar && !(SVX_EXP_P0 & 1)) {
+#pragma unroll
+                for (int g4 = 0; g4 < EPL / 4; g4++) {
+                    const float4 t = *reinterpret_cast<const float4*>(rb_l + (g4 * SVX_WAVE + lane) * 4);
+                    da += xa[4 * g4] * t.x; da += xa[4 * g4 + 1] * t.y; da += xa[4 * g4 + 2] * t.z; da += xa[4 * g4 + 3] * t.w;
+                    db += xb[4 * g4] * t.x; db += xb[4 * g4 + 1] * t.y; db += xb[4 * g4 + 2] * t.z; db += xb[4 * g4 + 3] * t.w;
+                }
+            }
+            // ---- one butterfly for the four sums
+            float q;
+            if (SVX_EXP_P0 & 4) q = ssa + ssb + da + db + 1.0f;
+            else {
+                const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ssa), __float_as_uint(ssb), false, false);
+                const float S = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);   // lanes 0-31: a, lanes 32-63: b
+                const auto d32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(da), __float_as_uint(db), false, false);
+                const float D = __uint_as_float(d32[0]) + __uint_as_float(d32[1]);
+                const auto q16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(S), __float_as_uint(D), false, false);
+                q = __uint_as_float(q16[0]) + __uint_as_float(q16[1]);   // 16-lane rows: ss(a), dot(a), ss(b), dot(b)
+                q += SVX_DPP_F32(q, 0xB1);
+                q += SVX_DPP_F32(q, 0x4E);
+                q += SVX_DPP_F32(q, 0x141);
+                q += SVX_DPP_F32(q, 0x140);
+            }
+            const float rd_v = (SVX_EXP_P0 & 4) ? q : 1.0f / (sqrtf(q) + 1e-5f);   // meaningful in the ss rows
+            const float rden_a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rd_v), 0));
+            const float rden_b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rd_v), 32));
+            if (lane == 0) {
+                gst(inv_out + ra, rden_a);
+                if (has_b) gst(inv_out + ra + 1, rden_b);
+            }
+            if (nrm_out) {
+                const float dta = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q), 16));
+                const float dtb = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q), 48));
+                if (lane == 0) {
+                    gst(nrm_out + ra, (SVX_EXP_P0 & 5) ? 1.0f : 1.0f - rden_a * dta);
+                    if (has_b) gst(nrm_out + ra + 1, (SVX_EXP_P0 & 5) ? 1.0f : 1.0f - rden_b * dtb);
+                }
+            }
+            if (part_out && ra + 1 < npairs_rows && !(SVX_EXP_P0 & 2)) {
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    const float pa = xa[e] * rden_a, pb = xb[e] * rden_b;  // the products and the sum of pair_row
+                    const float sum = pa + pb;
+                    cs[e] += sum;
+                }
+            }
+        }
+    }
+    if (part_out) {
+        // fixed-order reduction over the 4 waves -> deterministic partial
+#pragma unroll
+        for (int e = 0; e < EPL; e++) red[(w * EPL + e) * SVX_WAVE + lane] = cs[e];
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < EPL * SVX_WAVE; idx += blockDim.x) {
+            const int e = idx / SVX_WAVE, l = idx % SVX_WAVE;
+            const int col = R::col_of(e, l);
+            if (col < d) {
+                float sum = red[(0 * EPL + e) * SVX_WAVE + l];
+                sum += red[(1 * EPL + e) * SVX_WAVE + l];
+                sum += red[(2 * EPL + e) * SVX_WAVE + l];
+                sum += red[(3 * EPL + e) * SVX_WAVE + l];
+                gst(part_out + col, sum);
             }
         }
     }
@@ -326,8 +468,15 @@ __device__ void sample_mean_block(const typename E::storage* base, int K, int n,
 // ---------------------------------------------------------------- fused-pipeline kernels
 // MODE 0: levels >= 2 (fp32 pair sums of the level above), 1: level 0 (the inputs), 2: level 1, rows formed from
 // the level-0 inputs and their 1/norm on the fly.
-template <typename E, int NCH, int MODE>
-__global__ __launch_bounds__(256) void k_pyramid(const SvxPairDev* __restrict__ pairs, int level) {
+#ifndef SVX_PYR_MINW
+#define SVX_PYR_BOUNDS __launch_bounds__(256)
+#else
+#define SVX_PYR_BOUNDS __launch_bounds__(256, SVX_PYR_MINW)
+#endif
+// FULL: d == NCH * 64 * E::VEC, every lane of every piece is inside the row (the launcher checks it): the loads and
+// stores need no per-lane range test.
+template <typename E, int NCH, int MODE, bool FULL>
+__global__ SVX_PYR_BOUNDS void k_pyramid(const SvxPairDev* __restrict__ pairs, int level) {
     constexpr bool LV0 = MODE == 1;
     __shared__ float lds[6 * NCH * E::VEC * SVX_WAVE];
     const SvxPairDev& P = pairs[blockIdx.z];
@@ -359,7 +508,17 @@ __global__ __launch_bounds__(256) void k_pyramid(const SvxPairDev* __restrict__ 
     const bool has_next = level < P.L;
     float* next = (has_next && !LV0) ? P.lev[level + 1].P[side] + (size_t)k * (n / 2) * d : nullptr;
     float* part = has_next ? P.lev[level + 1].part[side] + ((size_t)k * Lv.nblk[side] + blockIdx.x) * d : nullptr;
-    pyr_block<E, NCH, MODE == 2>(rows, n, d, mean, rbar, inv_out, nrm_out, vn_out, next, part, blockIdx.x, lds, inv0);
+#ifndef SVX_PYR_NT
+#define SVX_PYR_NT 0   // bit 0: level 0, bit 1: level 1, bit 2: levels >= 2 read their rows with non-temporal loads
+#endif
+    constexpr bool NT = ((SVX_PYR_NT >> (MODE == 1 ? 0 : (MODE == 2 ? 1 : 2))) & 1) != 0;
+#ifndef SVX_PYR0_GENERIC
+    if constexpr (LV0) {
+        pyr0_block<E, NCH, FULL>(rows, n, d, rbar, inv_out, nrm_out, part, blockIdx.x, lds);
+        return;
+    }
+#endif
+    pyr_block<E, NCH, MODE == 2, NT, FULL>(rows, n, d, mean, rbar, inv_out, nrm_out, vn_out, next, part, blockIdx.x, lds, inv0);
 }
 
 __global__ __launch_bounds__(256) void k_colmean(const SvxPairDev* __restrict__ pairs, int level) {
@@ -659,7 +818,8 @@ int svxl_pyramid_level(svx_ctx* ctx, const SvxPairDev* pairs, int n_pairs, int l
 #define LAUNCH(E, N, MODE)                                                                                             \
     do {                                                                                                               \
         if (part == 0) hipLaunchKernelGGL((k_sample_mean<E, N, MODE>), dim3(2, n_pairs), dim3(256), 0, st, pairs, level); \
-        else hipLaunchKernelGGL((k_pyramid<E, N, MODE>), dim3(max_nblk, max_ksum, n_pairs), dim3(256), 0, st, pairs, level); \
+        else if (d == N * E::VEC * SVX_WAVE) hipLaunchKernelGGL((k_pyramid<E, N, MODE, true>), dim3(max_nblk, max_ksum, n_pairs), dim3(256), 0, st, pairs, level); \
+        else hipLaunchKernelGGL((k_pyramid<E, N, MODE, false>), dim3(max_nblk, max_ksum, n_pairs), dim3(256), 0, st, pairs, level); \
     } while (0)
     const int mode = level == 0 ? 1 : (level == 1 ? 2 : 0);
     if (mode == 0) {

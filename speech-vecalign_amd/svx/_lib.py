@@ -5,7 +5,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvx.so")
+LIB_PATH = os.environ.get("SVX_LIB") or os.path.join(_HERE, "libsvx.so")   # (SVX_LIB: A/B builds, profiles/build_variant.sh)
 
 SVX_F32, SVX_F16, SVX_BF16 = 0, 1, 2
 SVX_MAX_TYPES = 128

@@ -145,16 +145,18 @@ def test_pipeline_does_not_change_results():
     types = alignment_types(4)
     docs = [make_pair(500 + 37 * i, 520 - 11 * i, 3, 64, 60 + i) for i in range(5)]
     more = [make_pair(900 - 50 * i, 700 + 90 * i, 3, 64, 80 + i) for i in range(4)]
+    # enough pairs for the pipeline to cut its pyramid passes into slices (>= 32 per half), three levels each
+    many = [make_pair(330 + (7 * i) % 90, 310 + (11 * i) % 70, 3, 32, 300 + i) for i in range(71)]
     ctx = _lib.context()
 
     def sequence():
         outs = []
         mk = lambda ds, s0: dp_utils.PreparedBatch(ds, types, 0.2, 7, 300, 20000, 100, rngs=[np.random.RandomState(s0 + i) for i in range(len(ds))])
-        a, b, c = mk(docs, 0), mk(more, 100), mk(docs[:1], 200)
-        for pb in (a, a, b, c, a):     # every run() overlaps the chain the one before it held back
+        a, b, c, m = mk(docs, 0), mk(more, 100), mk(docs[:1], 200), mk(many, 400)
+        for pb in (a, a, b, m, m, c, m, a):     # every run() overlaps the chain the one before it held back
             pb.run()
         a.flush()
-        for pb in (a, b, c):
+        for pb in (a, b, c, m):
             outs.append(pb.results())
         outs.append(a.level_stack(4, 0)['a_b_csum'])   # a pair of the second (held-back) half
         return outs
@@ -165,11 +167,11 @@ def test_pipeline_does_not_change_results():
         piped = sequence()
     finally:
         ctx.set_pipeline(False)
-    for o, q in zip(plain[:3], piped[:3]):
+    for o, q in zip(plain[:4], piped[:4]):
         assert len(o) == len(q)
         for x, y in zip(o, q):
             assert x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
-    assert np.array_equal(plain[3], piped[3])
+    assert np.array_equal(plain[4], piped[4])
 
 
 def test_phase_timing_log_like_the_reference():
