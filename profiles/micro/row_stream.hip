@@ -21,7 +21,7 @@ template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // MODE 0: registers, 1: LDS-DMA, 2: registers, non-temporal.  WRITE: fp32 "pair sums" of every two rows go out (4 KB per 4 KB read)
-template <int MODE, int DEPTH, bool WRITE, int PAD_KB = 0>
+template <int MODE, int DEPTH, bool WRITE, int PAD_KB = 0, int PAT = 0>
 __global__ __launch_bounds__(64 * WAVES) void k_rows(const char* __restrict__ src, long rows, float* __restrict__ dst, float* __restrict__ sums) {
     __shared__ __attribute__((aligned(1024))) char lds[MODE == 1 ? WAVES * DEPTH * ROWB : 16];
     __shared__ char pad[PAD_KB > 0 ? PAD_KB * 1024 : 16];   // PAD_KB: limits the workgroups per CU (160 KB of LDS) like the pyramid kernels' registers do
@@ -59,11 +59,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_rows(const char* __restrict__ sr
 #pragma unroll
             for (int i = 0; i < 8; i++) { acc += v[i]; ps[i] = (r & 1) ? ps[i] + v[i] : v[i]; }
             if (WRITE && (r & 1)) {
-                float* o = dst + ((r0 + r) / 2) * 1024 + lane * 4;
+                // PAT 0: an instruction's 64 lanes write 1 KB contiguous; PAT 1: a lane owns 32 contiguous bytes and writes them
+                // with two instructions (each instruction then covers 16-byte pieces at a 32-byte stride: k_pyramid's stores)
+                float* o = dst + ((r0 + r) / 2) * 1024 + (PAT == 1 ? lane * 8 : lane * 4);
                 __builtin_nontemporal_store((f32x4_t){ps[0], ps[1], ps[2], ps[3]}, (__attribute__((address_space(1))) f32x4_t*)o);
-                __builtin_nontemporal_store((f32x4_t){ps[4], ps[5], ps[6], ps[7]}, (__attribute__((address_space(1))) f32x4_t*)(o + 256));
+                __builtin_nontemporal_store((f32x4_t){ps[4], ps[5], ps[6], ps[7]}, (__attribute__((address_space(1))) f32x4_t*)(o + (PAT == 1 ? 4 : 256)));
                 __builtin_nontemporal_store((f32x4_t){ps[1], ps[0], ps[3], ps[2]}, (__attribute__((address_space(1))) f32x4_t*)(o + 512));
-                __builtin_nontemporal_store((f32x4_t){ps[5], ps[4], ps[7], ps[6]}, (__attribute__((address_space(1))) f32x4_t*)(o + 768));
+                __builtin_nontemporal_store((f32x4_t){ps[5], ps[4], ps[7], ps[6]}, (__attribute__((address_space(1))) f32x4_t*)(o + (PAT == 1 ? 516 : 768)));
             }
         }
     } else {
@@ -89,26 +91,28 @@ __global__ __launch_bounds__(64 * WAVES) void k_rows(const char* __restrict__ sr
 #pragma unroll
             for (int i = 0; i < 8; i++) { acc += v[i]; ps[i] = (r & 1) ? ps[i] + v[i] : v[i]; }
             if (WRITE && (r & 1)) {
-                float* o = dst + ((r0 + r) / 2) * 1024 + lane * 4;
+                // PAT 0: an instruction's 64 lanes write 1 KB contiguous; PAT 1: a lane owns 32 contiguous bytes and writes them
+                // with two instructions (each instruction then covers 16-byte pieces at a 32-byte stride: k_pyramid's stores)
+                float* o = dst + ((r0 + r) / 2) * 1024 + (PAT == 1 ? lane * 8 : lane * 4);
                 __builtin_nontemporal_store((f32x4_t){ps[0], ps[1], ps[2], ps[3]}, (__attribute__((address_space(1))) f32x4_t*)o);
-                __builtin_nontemporal_store((f32x4_t){ps[4], ps[5], ps[6], ps[7]}, (__attribute__((address_space(1))) f32x4_t*)(o + 256));
+                __builtin_nontemporal_store((f32x4_t){ps[4], ps[5], ps[6], ps[7]}, (__attribute__((address_space(1))) f32x4_t*)(o + (PAT == 1 ? 4 : 256)));
                 __builtin_nontemporal_store((f32x4_t){ps[1], ps[0], ps[3], ps[2]}, (__attribute__((address_space(1))) f32x4_t*)(o + 512));
-                __builtin_nontemporal_store((f32x4_t){ps[5], ps[4], ps[7], ps[6]}, (__attribute__((address_space(1))) f32x4_t*)(o + 768));
+                __builtin_nontemporal_store((f32x4_t){ps[5], ps[4], ps[7], ps[6]}, (__attribute__((address_space(1))) f32x4_t*)(o + (PAT == 1 ? 516 : 768)));
             }
         }
     }
     if (acc == 1.2345f) sums[0] = acc;
 }
 
-template <int MODE, int DEPTH, bool WRITE, int PAD_KB = 0>
+template <int MODE, int DEPTH, bool WRITE, int PAD_KB = 0, int PAT = 0>
 static void run(const char* what, const char* src, long rows, float* dst, float* sums) {
     const int grid = (int)((rows + WAVES * RPW - 1) / (WAVES * RPW));
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    k_rows<MODE, DEPTH, WRITE, PAD_KB><<<grid, 64 * WAVES>>>(src, rows, dst, sums);
+    k_rows<MODE, DEPTH, WRITE, PAD_KB, PAT><<<grid, 64 * WAVES>>>(src, rows, dst, sums);
     if (hipDeviceSynchronize() != hipSuccess) { printf("%s: failed\n", what); exit(2); }
     hipEventRecord(a);
-    for (int i = 0; i < 3; i++) k_rows<MODE, DEPTH, WRITE, PAD_KB><<<grid, 64 * WAVES>>>(src, rows, dst, sums);
+    for (int i = 0; i < 3; i++) k_rows<MODE, DEPTH, WRITE, PAD_KB, PAT><<<grid, 64 * WAVES>>>(src, rows, dst, sums);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms = 0;
@@ -138,6 +142,7 @@ int main() {
     run<0, 4, false, 50>("A  registers, 4 rows in flight, 3 workgroups (12 waves) per CU", src, rows, dst, sums);
     run<0, 4, true, 36>("A  4 rows in flight, 4 workgroups per CU, + streaming stores", src, rows, dst, sums);
     run<0, 4, true>("A  registers, 4 rows in flight, + streaming stores", src, rows, dst, sums);
+    run<0, 4, true, 36, 1>("A  4 workgroups per CU, + stores of 32 bytes per lane as 2 x 16", src, rows, dst, sums);
     run<2, 4, true>("C  non-temporal loads, + streaming stores", src, rows, dst, sums);
     run<1, 4, true>("B  LDS-DMA, 4 rows in flight, + streaming stores", src, rows, dst, sums);
     return 0;

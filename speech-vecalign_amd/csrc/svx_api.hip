@@ -821,7 +821,8 @@ static void front_ops(svx_ctx* ctx, HalfState& H, std::vector<Op>& ops, int spli
     auto sort_op = [=]() -> int {
         // the counting sort of the sampled (x, y) pairs only needs the descriptors: side stream, beside the pyramid
         hipStream_t main_stream = ctx->stream;
-        ctx->stream = cx->side;
+        static const bool inline_sort = getenv("SVX_SORT_INLINE") != nullptr;   // measurements: the sort in front of the pyramid instead of beside it
+        ctx->stream = inline_sort ? main_stream : cx->side;
         int rc;
         {
             StageScope sc(ctx, S_KNOB_SORT);  // (timed on the stream it runs on)
@@ -829,7 +830,7 @@ static void front_ops(svx_ctx* ctx, HalfState& H, std::vector<Op>& ops, int spli
         }
         ctx->stream = main_stream;
         if (rc) return rc;
-        SVX_HIP(ctx, hipEventRecord(cx->side_join, cx->side));
+        SVX_HIP(ctx, hipEventRecord(cx->side_join, inline_sort ? main_stream : cx->side));
         return SVX_OK;
     };
     if (parts == 1) ops.push_back({0.0, -1, sort_op});

@@ -108,6 +108,61 @@ __device__ __forceinline__ void pair_row(const typename E::storage* rows0, const
     }
 }
 
+// One float32 row out of lane registers laid out by the 16-BIT column map (a lane owns 8 consecutive elements = 32 bytes
+// of float32): stored straight from the registers, an instruction's 64 lanes write 16-byte pieces at a 32-byte stride --
+// half lines -- and the pass streams at 4.7 TB/s instead of 6.0 (profiles/micro/row_stream.hip, last variant).  Through
+// `wbuf` (EPL * 64 floats of LDS private to the wave: its slot of the column-sum area, unused until the epilogue) the
+// row is re-dealt so that every store instruction writes 1 KB contiguous.  No bank conflicts either way.
+template <typename R, bool FULL, bool NT>
+__device__ __forceinline__ void store_row_via_lds(float* dst, int d, int lane, const float* x, float* wbuf) {
+    constexpr int NCH = R::EPL / R::VEC;
+    static_assert(R::VEC == 8, "16-bit column map");
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        float4* w4 = reinterpret_cast<float4*>(wbuf + 512 * c + 8 * lane);
+        w4[0] = make_float4(x[8 * c + 0], x[8 * c + 1], x[8 * c + 2], x[8 * c + 3]);
+        w4[1] = make_float4(x[8 * c + 4], x[8 * c + 5], x[8 * c + 6], x[8 * c + 7]);
+    }
+#pragma unroll
+    for (int g = 0; g < 2 * NCH; g++) {
+        const int col = 256 * g + 4 * lane;
+        const float4 v = *reinterpret_cast<const float4*>(wbuf + col);
+        if (FULL || col < d) {
+            if (NT) gstf4_nt(dst + col, v.x, v.y, v.z, v.w);
+            else gstf4(dst + col, v.x, v.y, v.z, v.w);
+        }
+    }
+}
+
+// LDS floats a pyramid workgroup needs: mean and rbar (lane-major), the four waves' column sums, the arrival counter.
+#define SVX_PYR_LDS_FLOATS(NCH, VEC) (6 * (NCH) * (VEC) * SVX_WAVE + 4)
+
+// Column-sum partial of a workgroup WITHOUT a barrier: every wave drops its sums into LDS and draws a ticket; the
+// wave that draws the last one adds the four in wave order (so the partial is deterministic) and stores the row.
+// A barrier here kept three finished waves -- and their registers -- parked until the slowest one arrived, with none of
+// the workgroup's loads in flight meanwhile: 1.15 of the level-0 pass's 13.1 ms.  `arrive` is zeroed by the caller
+// before its first __syncthreads().
+template <typename R, bool FULL>
+__device__ __forceinline__ void part_epilogue(float* red, int* arrive, const float* cs, float* part_out, int d, int lane, int w) {
+    constexpr int EPL = R::EPL;
+#pragma unroll
+    for (int e = 0; e < EPL; e++) red[(w * EPL + e) * SVX_WAVE + lane] = cs[e];
+    int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);  // behind this wave's writes
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != 3) return;
+    float sum[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+        float t = red[(0 * EPL + e) * SVX_WAVE + lane];
+        t += red[(1 * EPL + e) * SVX_WAVE + lane];
+        t += red[(2 * EPL + e) * SVX_WAVE + lane];
+        t += red[(3 * EPL + e) * SVX_WAVE + lane];
+        sum[e] = t;
+    }
+    R::template storef<FULL>(part_out, d, lane, sum);
+}
+
 // A logical row as it comes out of memory: raw 16-byte pieces (converted when the row is used, so that several
 // rows can be in flight in few registers).  PAIR: the row is the sum of two scaled level-0 rows (pair_row).
 template <typename E, int NCH, bool PAIR>
@@ -177,6 +232,8 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
     float* mu_l = lds;
     float* rb_l = lds + DP;
     float* red = lds + 2 * DP;
+    int* arrive = reinterpret_cast<int*>(lds + 6 * DP);
+    if (threadIdx.x == 0) *arrive = 0;
     // mean / rbar are kept lane-major: the 16-byte group g of lane l sits at float4 index g * 64 + l, so that a
     // wave's ds_read_b128 touches consecutive addresses (the row's own column map would stride them by VEC floats)
     for (int c = threadIdx.x; c < DP; c += blockDim.x) {
@@ -202,20 +259,28 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
     int r1 = r0 + 2 * (SVX_PYR_SLOTS / 4);   // this wave's rows: [r0, r1)
     r1 = r1 < n ? r1 : n;
     float xs[EPL];   // running pair sum
+    // a row's scalars (1/norm, n0 / n1) wait in lane (row - r0) and leave as ONE store of up to 16 floats per wave at the
+    // end: a 4-byte store from one lane per row cost the level-0 pass 0.9 of its 13.1 ms
+    float keep_inv = 0.f, keep_nrm = 0.f;
     RawRow<E, NCH, PAIR> ring[DEPTH];
+    // The wave's rows are walked by STRAIGHT-LINE code (the trip count is a compile-time constant, the loads are
+    // unconditional with a clamped row index): in a loop the values loaded for the rows ahead reach the next iteration
+    // through register copies at the back edge, and the compiler waits for the loads in front of those copies -- every
+    // iteration drained the queue it had just filled (s_waitcnt vmcnt(0) right behind the prefetch).
+    constexpr int RPWV = 2 * (SVX_PYR_SLOTS / 4);
+    static_assert(RPWV % DEPTH == 0, "whole ring revolutions");
+    const int rl = r1 - 1;   // last row of this wave
+    if (r0 < r1) {           // wave-uniform
 #pragma unroll
-    for (int s = 0; s < DEPTH; s++)
-        if (r0 + s < r1) fetch_raw<E, NCH, PAIR, NT, FULL>(rows, inv0, r0 + s, d, lane, ring[s]);
-#pragma unroll 1
-    for (int rb = r0; rb < r1; rb += DEPTH) {
+        for (int s = 0; s < DEPTH; s++) fetch_raw<E, NCH, PAIR, NT, FULL>(rows, inv0, (r0 + s) < rl ? (r0 + s) : rl, d, lane, ring[s]);
 #pragma unroll
-        for (int s = 0; s < DEPTH; s++) {
-            const int r = rb + s;
-            if (r >= r1) break;  // wave-uniform
-            const int jp = r >> 1, half = r & 1;
+        for (int i = 0; i < RPWV; i++) {
+            const int r = r0 + i, s = i % DEPTH;
+            const int jp = r >> 1, half = i & 1;   // (r0 is even)
             float x[EPL];
             decode_raw<E, NCH, PAIR>(ring[s], x);
-            if (r + DEPTH < r1) fetch_raw<E, NCH, PAIR, NT, FULL>(rows, inv0, r + DEPTH, d, lane, ring[s]);
+            if (i + DEPTH < RPWV) fetch_raw<E, NCH, PAIR, NT, FULL>(rows, inv0, (r + DEPTH) < rl ? (r + DEPTH) : rl, d, lane, ring[s]);
+            if (r >= r1) continue;  // wave-uniform (a partial wave at the end of a layer)
             if (mean) {
                 float mu[EPL];
                 lane_major(mu_l, mu);
@@ -230,22 +295,20 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
             const float rden = 1.0f / den;  // one division per row; the elements are scaled by the reciprocal
 #pragma unroll
             for (int e = 0; e < EPL; e++) x[e] = x[e] * rden;
-#ifdef SVX_EXP_NODOT
-            if (lane == 0 && nrm_out) gst(nrm_out + r, 1.0f);   // (timing experiment: the dot product with rbar and its reduction left out)
-            if (false) {
-#else
             if (rbar) {
-#endif
                 float rbv[EPL];
                 lane_major(rb_l, rbv);
                 float dt = 0.f;
 #pragma unroll
                 for (int e = 0; e < EPL; e++) dt += x[e] * rbv[e];
                 dt = wave_sum(dt);
-                if (lane == 0 && nrm_out) gst(nrm_out + r, 1.0f - dt);
+                keep_nrm = lane == i ? 1.0f - dt : keep_nrm;
             }
-            if (lane == 0 && inv_out) gst(inv_out + r, rden);
-            if (vn_out) R::template storef<FULL>(vn_out + (size_t)r * d, d, lane, x);
+            keep_inv = lane == i ? rden : keep_inv;
+            if (vn_out) {
+                if constexpr (E::VEC == 8) store_row_via_lds<R, FULL, false>(vn_out + (size_t)r * d, d, lane, x, red + w * EPL * SVX_WAVE);
+                else R::template storef<FULL>(vn_out + (size_t)r * d, d, lane, x);
+            }
             if (next || part_out) {  // (the level-0 pass keeps only the column sums: level 1 re-forms its rows)
                 if (half == 0) {
 #pragma unroll
@@ -256,28 +319,19 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
                         xs[e] = xs[e] + x[e];
                         cs[e] += xs[e];
                     }
-                    if (next) R::template storef_nt<FULL>(next + (size_t)jp * d, d, lane, xs);
+                    if (next) {
+                        if constexpr (E::VEC == 8) store_row_via_lds<R, FULL, true>(next + (size_t)jp * d, d, lane, xs, red + w * EPL * SVX_WAVE);
+                        else R::template storef_nt<FULL>(next + (size_t)jp * d, d, lane, xs);
+                    }
                 }
             }
         }
     }
-    if (part_out) {
-        // fixed-order reduction over the 4 waves -> deterministic partial
-#pragma unroll
-        for (int e = 0; e < EPL; e++) red[(w * EPL + e) * SVX_WAVE + lane] = cs[e];
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < EPL * SVX_WAVE; idx += blockDim.x) {
-            const int e = idx / SVX_WAVE, l = idx % SVX_WAVE;
-            const int col = R::col_of(e, l);
-            if (col < d) {
-                float s = red[(0 * EPL + e) * SVX_WAVE + l];
-                s += red[(1 * EPL + e) * SVX_WAVE + l];
-                s += red[(2 * EPL + e) * SVX_WAVE + l];
-                s += red[(3 * EPL + e) * SVX_WAVE + l];
-                gst(part_out + col, s);
-            }
-        }
+    if (lane < RPWV && r0 + lane < r1) {
+        if (inv_out) gst(inv_out + r0 + lane, keep_inv);
+        if (nrm_out && rbar) gst(nrm_out + r0 + lane, keep_nrm);
     }
+    if (part_out) part_epilogue<R, FULL>(red, arrive, cs, part_out, d, lane, w);
 }
 
 // ---------------------------------------------------------------- level 0, lean
@@ -301,6 +355,9 @@ __device__ void pyr0_block(const typename E::storage* rows, int n, int d, const 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float* rb_l = lds;            // rbar, lane-major (see pyr_block)
     float* red = lds + 2 * DP;
+    int* arrive = reinterpret_cast<int*>(lds + 6 * DP);
+    if (threadIdx.x == 0) *arrive = 0;
+    float keep_inv = 0.f, keep_nrm = 0.f;   // the rows' scalars, one per lane, stored once per wave (see pyr_block)
     if (rbar) {
         for (int c = threadIdx.x; c < DP; c += blockDim.x) {
             const int ch = c / (SVX_WAVE * E::VEC), l = (c / E::VEC) % SVX_WAVE, i = c % E::VEC;
@@ -313,37 +370,39 @@ __device__ void pyr0_block(const typename E::storage* rows, int n, int d, const 
     int r1 = r0 + 2 * (SVX_PYR_SLOTS / 4);
     r1 = r1 < n ? r1 : n;
     RawRow<E, NCH, false> ring[DEPTH];
+    constexpr int RPWV = 2 * (SVX_PYR_SLOTS / 4);   // straight-line code over the wave's rows: see pyr_block
+    static_assert(RPWV % DEPTH == 0, "whole ring revolutions");
+    const int rl = r1 - 1;
+    if (r0 < r1) {
 #pragma unroll
-    for (int s = 0; s < DEPTH; s++)
-        if (r0 + s < r1) fetch_raw<E, NCH, false, false, FULL>(rows, nullptr, r0 + s, d, lane, ring[s]);
+        for (int s = 0; s < DEPTH; s++) fetch_raw<E, NCH, false, false, FULL>(rows, nullptr, (r0 + s) < rl ? (r0 + s) : rl, d, lane, ring[s]);
+    }
     __syncthreads();   // rbar is staged (the rows' loads are already in flight)
     float cs[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; e++) cs[e] = 0.f;
     const int npairs_rows = 2 * (n / 2);   // rows that have a partner (an odd last row only gets its scalars)
-#pragma unroll 1
-    for (int rb = r0; rb < r1; rb += DEPTH) {
+    if (r0 < r1) {
 #pragma unroll
-        for (int s = 0; s < DEPTH; s += 2) {
-            const int ra = rb + s;
-            if (ra >= r1) break;  // wave-uniform
+        for (int i = 0; i < RPWV; i += 2) {
+            const int ra = r0 + i, s = i % DEPTH;
             const bool has_b = ra + 1 < r1;
             float xa[EPL], xb[EPL];
             decode_raw<E, NCH, false>(ring[s], xa);
             decode_raw<E, NCH, false>(ring[s + 1], xb);
+            if (i + DEPTH < RPWV) {
+                fetch_raw<E, NCH, false, false, FULL>(rows, nullptr, (ra + DEPTH) < rl ? (ra + DEPTH) : rl, d, lane, ring[s]);
+                fetch_raw<E, NCH, false, false, FULL>(rows, nullptr, (ra + 1 + DEPTH) < rl ? (ra + 1 + DEPTH) : rl, d, lane, ring[s + 1]);
+            }
+            if (ra >= r1) continue;  // wave-uniform
             if (!has_b) {
 #pragma unroll
                 for (int e = 0; e < EPL; e++) xb[e] = 0.f;
             }
-            if (ra + DEPTH < r1) fetch_raw<E, NCH, false, false, FULL>(rows, nullptr, ra + DEPTH, d, lane, ring[s]);
-            if (ra + 1 + DEPTH < r1) fetch_raw<E, NCH, false, false, FULL>(rows, nullptr, ra + 1 + DEPTH, d, lane, ring[s + 1]);
             float ssa = 0.f, ssb = 0.f, da = 0.f, db = 0.f;
 #pragma unroll
             for (int e = 0; e < EPL; e++) { ssa += xa[e] * xa[e]; ssb += xb[e] * xb[e]; }
-#ifndef SVX_EXP_P0
-#define SVX_EXP_P0 0   // timing experiments only (bit 0: no dot with rbar, bit 1: no column sums, bit 2: no butterfly / sqrt)
-#endif
-            if (rbar && !(SVX_EXP_P0 & 1)) {
+            if (rbar) {
 #pragma unroll
                 for (int g4 = 0; g4 < EPL / 4; g4++) {
                     const float4 t = *reinterpret_cast<const float4*>(rb_l + (g4 * SVX_WAVE + lane) * 4);
@@ -353,8 +412,7 @@ __device__ void pyr0_block(const typename E::storage* rows, int n, int d, const 
             }
             // ---- one butterfly for the four sums
             float q;
-            if (SVX_EXP_P0 & 4) q = ssa + ssb + da + db + 1.0f;
-            else {
+            {
                 const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ssa), __float_as_uint(ssb), false, false);
                 const float S = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);   // lanes 0-31: a, lanes 32-63: b
                 const auto d32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(da), __float_as_uint(db), false, false);
@@ -366,22 +424,16 @@ __device__ void pyr0_block(const typename E::storage* rows, int n, int d, const 
                 q += SVX_DPP_F32(q, 0x141);
                 q += SVX_DPP_F32(q, 0x140);
             }
-            const float rd_v = (SVX_EXP_P0 & 4) ? q : 1.0f / (sqrtf(q) + 1e-5f);   // meaningful in the ss rows
+            const float rd_v = 1.0f / (sqrtf(q) + 1e-5f);   // meaningful in the ss rows
             const float rden_a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rd_v), 0));
             const float rden_b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rd_v), 32));
-            if (lane == 0) {
-                gst(inv_out + ra, rden_a);
-                if (has_b) gst(inv_out + ra + 1, rden_b);
-            }
+            keep_inv = lane == i ? rden_a : (lane == i + 1 ? rden_b : keep_inv);
             if (nrm_out) {
                 const float dta = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q), 16));
                 const float dtb = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q), 48));
-                if (lane == 0) {
-                    gst(nrm_out + ra, (SVX_EXP_P0 & 5) ? 1.0f : 1.0f - rden_a * dta);
-                    if (has_b) gst(nrm_out + ra + 1, (SVX_EXP_P0 & 5) ? 1.0f : 1.0f - rden_b * dtb);
-                }
+                keep_nrm = lane == i ? 1.0f - rden_a * dta : (lane == i + 1 ? 1.0f - rden_b * dtb : keep_nrm);
             }
-            if (part_out && ra + 1 < npairs_rows && !(SVX_EXP_P0 & 2)) {
+            if (part_out && ra + 1 < npairs_rows) {
 #pragma clang fp contract(off)
 #pragma unroll
                 for (int e = 0; e < EPL; e++) {
@@ -392,23 +444,11 @@ __device__ void pyr0_block(const typename E::storage* rows, int n, int d, const 
             }
         }
     }
-    if (part_out) {
-        // fixed-order reduction over the 4 waves -> deterministic partial
-#pragma unroll
-        for (int e = 0; e < EPL; e++) red[(w * EPL + e) * SVX_WAVE + lane] = cs[e];
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < EPL * SVX_WAVE; idx += blockDim.x) {
-            const int e = idx / SVX_WAVE, l = idx % SVX_WAVE;
-            const int col = R::col_of(e, l);
-            if (col < d) {
-                float sum = red[(0 * EPL + e) * SVX_WAVE + l];
-                sum += red[(1 * EPL + e) * SVX_WAVE + l];
-                sum += red[(2 * EPL + e) * SVX_WAVE + l];
-                sum += red[(3 * EPL + e) * SVX_WAVE + l];
-                gst(part_out + col, sum);
-            }
-        }
+    if (lane < RPWV && r0 + lane < r1) {
+        gst(inv_out + r0 + lane, keep_inv);
+        if (nrm_out) gst(nrm_out + r0 + lane, keep_nrm);
     }
+    if (part_out) part_epilogue<R, FULL>(red, arrive, cs, part_out, d, lane, w);
 }
 
 // Mean of K*S sampled rows (optionally mean-subtracted and unit-normalised first).
@@ -478,7 +518,7 @@ __device__ void sample_mean_block(const typename E::storage* base, int K, int n,
 template <typename E, int NCH, int MODE, bool FULL>
 __global__ SVX_PYR_BOUNDS void k_pyramid(const SvxPairDev* __restrict__ pairs, int level) {
     constexpr bool LV0 = MODE == 1;
-    __shared__ float lds[6 * NCH * E::VEC * SVX_WAVE];
+    __shared__ float lds[SVX_PYR_LDS_FLOATS(NCH, E::VEC)];
     const SvxPairDev& P = pairs[blockIdx.z];
     if (level > P.L) return;
     int side, k;
@@ -571,7 +611,7 @@ __global__ __launch_bounds__(256) void k_sample_mean(const SvxPairDev* __restric
 template <int NCH>
 __global__ __launch_bounds__(256) void k_norm1_plain(float* vecs, int64_t rows, int d, const float* mean) {
     // make_norm1 over a flat [rows][d] tensor, in place; treats consecutive rows as pair slots
-    __shared__ float lds[6 * NCH * 4 * SVX_WAVE];
+    __shared__ float lds[SVX_PYR_LDS_FLOATS(NCH, 4)];
     int64_t nslots_total = (rows + 1) / 2;
     int64_t blk = blockIdx.x;
     if (blk * SVX_PYR_SLOTS >= nslots_total) return;
@@ -643,7 +683,7 @@ __global__ void k_colmean_plain(const float* part, int nblk, int d, int count, f
 template <int NCH>
 __global__ __launch_bounds__(256) void k_subnorm_plain(float* half, int h, int d, const float* mean) {
     // grid (nblk, k): half[k][j] = (half[k][j] - mean[k]) / (||.|| + 1e-5), in place
-    __shared__ float lds[6 * NCH * 4 * SVX_WAVE];
+    __shared__ float lds[SVX_PYR_LDS_FLOATS(NCH, 4)];
     const int k = blockIdx.y;
     float* base = half + (size_t)k * h * d;
     pyr_block<ElemF32, NCH>(base, h, d, mean + (size_t)k * d, nullptr, nullptr, nullptr, base, nullptr, nullptr,
