@@ -5,7 +5,7 @@ TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/r3
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r3/kt_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no_profile --cpu_pairs 0 --cpu_procs 0 --e2e_pairs 0 --e2e_files 0 "$@" > $R/gpurun_out/r3/kt_$TAG.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r3/kt_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no_profile --cpu_pairs 0 --cpu_procs 0 --e2e_pairs 0 --e2e_files 0 --extra_workloads 0 "$@" > $R/gpurun_out/r3/kt_$TAG.log 2>&1
 cd $R
 python3 - $TAG <<'PY'
 import csv, glob, re, sys

@@ -92,6 +92,7 @@ struct svx_ctx_ext : svx_ctx {
     size_t ev_next;
     // side stream: small latency-bound kernels that do not depend on the streaming passes (the sample sort)
     hipStream_t side;
+    hipStream_t helper;        // the pyramid's small per-level helpers (high priority: a pass on the context's stream waits for them)
     hipEvent_t side_fork, side_join;
     bool side_ready;
     int last_ntypes, last_band;  // of the last svx_align_batch call (svx_debug_level)
@@ -172,6 +173,8 @@ int svx_destroy(svx_ctx* ctx) {
     if (c->side_ready) {
         (void)hipStreamSynchronize(c->side);
         (void)hipStreamDestroy(c->side);
+        (void)hipStreamSynchronize(c->helper);
+        (void)hipStreamDestroy(c->helper);
         (void)hipEventDestroy(c->side_fork);
         (void)hipEventDestroy(c->side_join);
     }
@@ -226,7 +229,7 @@ static void fold_pending(svx_ctx_ext* c) {
     if (c->pending.empty()) return;
     (void)svx_flush(c);
     (void)hipStreamSynchronize(c->stream);
-    if (c->side_ready) (void)hipStreamSynchronize(c->side);
+    if (c->side_ready) { (void)hipStreamSynchronize(c->side); (void)hipStreamSynchronize(c->helper); }
     for (auto& r : c->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->acc_ms[r.stage] += ms; }
@@ -816,12 +819,15 @@ static void front_ops(svx_ctx* ctx, HalfState& H, std::vector<Op>& ops, int spli
     ops.push_back({0.0, -1, [=]() -> int {
         SVX_HIP(ctx, hipEventRecord(cx->side_fork, ctx->stream));
         SVX_HIP(ctx, hipStreamWaitEvent(cx->side, cx->side_fork, 0));
+        SVX_HIP(ctx, hipStreamWaitEvent(cx->helper, cx->side_fork, 0));
         return SVX_OK;
     }});
     auto sort_op = [=]() -> int {
         // the counting sort of the sampled (x, y) pairs only needs the descriptors: side stream, beside the pyramid
         hipStream_t main_stream = ctx->stream;
         static const bool inline_sort = getenv("SVX_SORT_INLINE") != nullptr;   // measurements: the sort in front of the pyramid instead of beside it
+        // sliced front: the sort starts once the level-0 pass (which its LDS atomics slow most) has left the chip
+        if (parts > 1 && !inline_sort) SVX_HIP(ctx, hipStreamWaitEvent(cx->side, evs->pass[0][parts - 1], 0));
         ctx->stream = inline_sort ? main_stream : cx->side;
         int rc;
         {
@@ -846,9 +852,9 @@ static void front_ops(svx_ctx* ctx, HalfState& H, std::vector<Op>& ops, int spli
             }
             ops.push_back({H.b_pyr[l] / (l == 0 ? 4.9e6 : 5.3e6) / parts, l == 0 ? S_PYR0 : (l == 1 ? S_PYR1 : S_PYRN), [=]() -> int {
                 hipStream_t main_stream = ctx->stream;
-                // the slice's helpers: side stream, behind the slice's pass of the level above
-                if (l > 0) SVX_HIP(ctx, hipStreamWaitEvent(cx->side, evs->pass[l - 1][q], 0));
-                ctx->stream = cx->side;
+                // the slice's helpers: helper stream, behind the slice's pass of the level above
+                if (l > 0) SVX_HIP(ctx, hipStreamWaitEvent(cx->helper, evs->pass[l - 1][q], 0));
+                ctx->stream = cx->helper;
                 int rc;
                 {
                     StageScope sc(ctx, S_PYR_AUX);
@@ -858,7 +864,7 @@ static void front_ops(svx_ctx* ctx, HalfState& H, std::vector<Op>& ops, int spli
                 if (rc) return rc;
                 hipEvent_t aux_done;
                 if ((rc = next_event(ctx, &aux_done))) return rc;
-                SVX_HIP(ctx, hipEventRecord(aux_done, cx->side));
+                SVX_HIP(ctx, hipEventRecord(aux_done, cx->helper));
                 SVX_HIP(ctx, hipStreamWaitEvent(main_stream, aux_done, 0));
                 if ((rc = svxl_pyramid_level(ctx, h->dpairs + lo, hi - lo, l, dtype, d, h->max_nblk[l], h->max_ksum, 1))) return rc;
                 if ((rc = next_event(ctx, &evs->pass[l][q]))) return rc;
@@ -866,7 +872,7 @@ static void front_ops(svx_ctx* ctx, HalfState& H, std::vector<Op>& ops, int spli
                 return SVX_OK;
             }});
         }
-        if (parts > 1 && l == 0) ops.push_back({0.0, -1, sort_op});   // (behind the level-0 helpers on the side stream)
+        if (parts > 1 && l == 0) ops.push_back({0.0, -1, sort_op});   // (beside the level-1 pass, which has vector-issue slots to spare)
     }
     if (!bp.straight) {
         // coarsest level: the dense 1-1 cost matrix, and with it the dot products its sampled scores need
@@ -944,6 +950,7 @@ static int ensure_streams(svx_ctx* ctx) {
         int prio_lo = 0, prio_hi = 0;
         SVX_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // (lowest, highest): the side work only fills gaps
         SVX_HIP(ctx, hipStreamCreateWithPriority(&cx->side, hipStreamNonBlocking, prio_lo));
+        SVX_HIP(ctx, hipStreamCreateWithPriority(&cx->helper, hipStreamNonBlocking, prio_hi));
         SVX_HIP(ctx, hipEventCreateWithFlags(&cx->side_fork, hipEventDisableTiming));
         SVX_HIP(ctx, hipEventCreateWithFlags(&cx->side_join, hipEventDisableTiming));
         cx->side_ready = true;
@@ -1141,7 +1148,7 @@ extern "C" int svx_align_batch(svx_ctx* ctx, const svx_align_params* prm, const 
         cx->acc_ms[S_HOST_LAUNCH] += cx->ms[S_HOST_LAUNCH];
     } else if (ctx->profiling) {
         if ((rc = svx_synchronize(ctx))) return rc;
-        if (cx->side_ready) SVX_HIP(ctx, hipStreamSynchronize(cx->side));
+        if (cx->side_ready) { SVX_HIP(ctx, hipStreamSynchronize(cx->side)); SVX_HIP(ctx, hipStreamSynchronize(cx->helper)); }
         for (auto& r : cx->recs) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) cx->ms[r.stage] += ms;
