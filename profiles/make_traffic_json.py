@@ -16,8 +16,8 @@ import json
 import re
 
 STAGE_OF = [  # (regex on the kernel name, stage)
-    (r"k_pyramid<Elem(BF16|F16|F32), \d+, 1>", "pyr0"), (r"k_pyramid<Elem(BF16|F16|F32), \d+, 2>", "pyr1"),
-    (r"k_pyramid<ElemF32, \d+, 0>", "pyrN"),
+    (r"k_pyramid<Elem(BF16|F16|F32), \d+, 1(, (true|false))?>", "pyr0"), (r"k_pyramid<Elem(BF16|F16|F32), \d+, 2(, (true|false))?>", "pyr1"),
+    (r"k_pyramid<ElemF32, \d+, 0(, (true|false))?>", "pyrN"),
     (r"k_knob_scores<Elem(BF16|F16|F32), \d+, true>", "knob_scores0"), (r"k_knob_scores<ElemF32, \d+, false>", "knob_scoresN"),
     (r"k_band_costs3<", "band_costs0"), (r"k_band_costs2<Elem(BF16|F16|F32), true", "band_costs0"),
     (r"k_band_costs2<ElemF32, false", "band_costsN"), (r"k_band_costs_batch<Elem(BF16|F16|F32), true", "band_costs0"),
@@ -29,7 +29,10 @@ STAGE_OF = [  # (regex on the kernel name, stage)
 ]
 
 
-def table(path, counter):
+PASSES = {"pyrN": 3, "band_costsN": 3, "band_dpN": 3}   # levels a stage's kernel runs over per step at the default workload (L = 4)
+
+
+def table(path, counter, counts=None):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
@@ -40,6 +43,8 @@ def table(path, counter):
                 agg[st][0] += 1
                 agg[st][1] += float(r["Counter_Value"])
                 break
+    if counts is not None:
+        counts.update({k: v[0] for k, v in agg.items()})
     return {k: v[1] / v[0] for k, v in agg.items()}
 
 
@@ -55,17 +60,23 @@ def main():
     ap.add_argument("--M", type=int, default=4096)
     ap.add_argument("--d", type=int, default=1024)
     ap.add_argument("--overlaps", type=int, default=4)
+    ap.add_argument("--steps_run", type=int, default=2, help="svx_align_batch calls in each counter run (warm-up + timed)")
     a = ap.parse_args()
-    f, w = table(a.fetch, "FETCH_SIZE"), table(a.write, "WRITE_SIZE")
+    counts = {}
+    f, w = table(a.fetch, "FETCH_SIZE", counts), table(a.write, "WRITE_SIZE")
+    # with the software pipeline a pass over the batch is several launches (half-batches, slices): pairs one launch covers
+    ppl = {st: a.pairs * PASSES.get(st, 1) / (counts[st] / float(a.steps_run)) for st in counts}
     out = {"pairs_per_step": a.pairs, "workload": a.workload, "dtype": a.dtype, "N": a.N, "M": a.M, "d": a.d, "overlaps": a.overlaps,
            "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes of `bench.py --steps 1 --warmup 1` at this "
-                  "pairs per step, profiles/run_profiles.sh); bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes)",
+                  "pairs per step, profiles/run_profiles.sh, software pipeline on); bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), launches averaged per stage",
+           "launches_per_step": {st: counts[st] / float(a.steps_run) for st in sorted(counts)},
+           "pairs_per_launch": {st: ppl[st] for st in sorted(ppl)},
            "hbm_bytes_per_launch": {st: (2 * f.get(st, 0.0) + w.get(st, 0.0)) * 1024 for st in sorted(set(f) | set(w))},
            "hbm_read_bytes_per_launch": {st: 2 * f[st] * 1024 for st in sorted(f)},
            "hbm_write_bytes_per_launch": {st: w[st] * 1024 for st in sorted(w)}}
     json.dump(out, open(a.out, "w"), indent=1)
     for st, b in sorted(out["hbm_bytes_per_launch"].items(), key=lambda kv: -kv[1]):
-        print("%-14s %8.2f GB per launch  (%6.1f MB per pair)" % (st, b / 1e9, b / a.pairs / 1e6))
+        print("%-14s %8.2f GB per launch  (%6.1f MB per pair per pass, %.0f pairs per launch)" % (st, b / 1e9, b / ppl.get(st, a.pairs) / 1e6, ppl.get(st, a.pairs)))
 
 
 if __name__ == "__main__":

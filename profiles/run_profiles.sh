@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
-ARGS="--cpu_pairs 0 --cpu_procs 0 --e2e_pairs 0 --e2e_files 0 $*"
+ARGS="--cpu_pairs 0 --cpu_procs 0 --e2e_pairs 0 --e2e_files 0 --extra_workloads 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py $ARGS > $O/kt.log 2>&1; echo exit=$? >> $O/kt.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no_profile $ARGS > $O/fetch.log 2>&1; echo exit=$? >> $O/fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 1 --warmup 1 --no_profile $ARGS > $O/write.log 2>&1; echo exit=$? >> $O/write.log
