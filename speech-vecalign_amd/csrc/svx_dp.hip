@@ -246,7 +246,10 @@ __device__ void sparse_dp_block(const SparseDpArgs& g, const SvxTypes& ty, doubl
 // holds +inf when the move is not allowed) and one word per node with its border case and the lanes of its two
 // deletion predecessors -- so that wave 0, which carries the serial chain, does no index arithmetic at all: per
 // type move two table reads, one ring read, one add and one compare.
-constexpr int DPF_THREADS = 256;
+#ifndef SVX_DPF_THREADS
+#define SVX_DPF_THREADS 256
+#endif
+constexpr int DPF_THREADS = SVX_DPF_THREADS;   // wave 0 sweeps, the others stage the next chunk's tables and flush the last one's results
 
 __host__ __device__ inline size_t dpf_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t dpf_chunk_bytes(int T, int B, int CH) {

@@ -305,7 +305,11 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--max_size", type=int, default=900, help="documents have 1 .. max_size-1 segments")
+    ap.add_argument("--pipeline", action="store_true", help="run the device side with the software pipeline on (svx_set_pipeline)")
     a = ap.parse_args()
+    if a.pipeline:
+        from svx import _lib
+        _lib.context().set_pipeline(True)
     if a.search == "straight":
         bad, _ = run_straight_sweep(a.cases, a.seed, min(a.batch, 6), max_size=a.max_size)
         sys.exit(1 if bad else 0)

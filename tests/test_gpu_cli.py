@@ -100,6 +100,33 @@ def test_cli_shards_partition_the_pair_list(tmp_path):
         get_shard_range(5, 2, 2)
 
 
+def test_cli_two_ranks_under_torchrun(tmp_path):
+    """The product's multi-process path as the launcher starts it: `torch.distributed.run --nproc-per-node 2 -m
+    svx.seg_align.align` -- two processes, rank and shard count taken from RANK / WORLD_SIZE, each on the device its
+    LOCAL_RANK names (both share the one GPU of this box; the alignment path has no collective, so no process group is
+    formed).  Together they write exactly the files of the unsharded run, byte for byte."""
+    import subprocess
+    import sys
+    root = str(tmp_path / "data")
+    build_tree(root, copies=4)
+    whole = str(tmp_path / "whole")
+    run_cli(root, whole, ["--fp16_embed", "--seed", "9"])
+    out = str(tmp_path / "ranks")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONPATH=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speech-vecalign_amd"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29683", "-m", "svx.seg_align.align", os.path.join(root, "metadata.tsv"), out, "--src_lang", "en",
+           "--tgt_lang", "de", "--seg_dir", os.path.join(root, "seg"), "--concat_dir", os.path.join(root, "cat"),
+           "--embed_dir", os.path.join(root, "emb"), "--ign_indices_dir", os.path.join(root, "ign"), "--fp16_embed", "--seed", "9"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    names = sorted(os.listdir(os.path.join(whole, "en-de")))
+    assert sorted(os.listdir(os.path.join(out, "en-de"))) == names and len(names) == 4
+    for n in names:
+        assert open(os.path.join(out, "en-de", n), "rb").read() == open(os.path.join(whole, "en-de", n), "rb").read()
+    assert "rank 0 of 2" in res.stderr + res.stdout and "rank 1 of 2" in res.stderr + res.stdout
+
+
 def test_cli_band_and_dense_modes(tmp_path):
     """--mode band / dense (additive flags): on the trimmed example the band around the straight diagonal and the whole
     lattice both contain the optimum the coarse-to-fine search finds, so all three modes print the same spans."""
