@@ -1269,18 +1269,16 @@ static int dpf_tpl(int T, int B) {
 
 static int dpf_choose_ch(int T, int B, int maxstep) {
     if (B > 64 || maxstep > 120) return 0;  // transitions are packed into 8-bit fields
-    const int opts[5] = {64, 32, 16, 8, 4};
+    const int opts[8] = {64, 48, 32, 24, 16, 12, 8, 4};
     // The sweep is latency-bound, so what matters is how many pairs a CU can host at once -- and, when the sweep runs
     // beside another half-batch's streaming kernels (svx_set_pipeline), that a workgroup fits into the LDS those leave
     // free: SVX_DP_LDS_KB (default 36: four workgroups per CU) bounds the chunk tables.
     static const int budget_kb = [] { const char* e = getenv("SVX_DP_LDS_KB"); const int v = e ? atoi(e) : 36; return v >= 6 ? v : 36; }();
-    for (int i = 0; i < 5; i++)
+    for (int i = 0; i < 8; i++)
         if (dpf_smem_bytes(T, B, maxstep + 1, opts[i]) <= (size_t)budget_kb * 1024) return opts[i];
-    for (int i = 0; i < 3; i++)
-        if (dpf_smem_bytes(T, B, maxstep + 1, opts[i]) <= 36 * 1024) return opts[i];
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < 5; i++)   // (>= 16 diagonals per chunk)
         if (dpf_smem_bytes(T, B, maxstep + 1, opts[i]) <= 52 * 1024) return opts[i];
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 8; i++)
         if (dpf_smem_bytes(T, B, maxstep + 1, opts[i]) <= 150 * 1024) return opts[i];
     return 0;
 }
