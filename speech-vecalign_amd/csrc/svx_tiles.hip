@@ -458,7 +458,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
         // (total, move index) with three DPP exchanges, so the reference's "first strictly smaller candidate" order holds.
         // Predecessors outside the lattice or the band, and the moves a slot does not have, read a +inf cell.
         {
-            constexpr int MS = (TT_MAXT + 2 + 7) / 8;  // moves per slot
+            constexpr int MS = (C::TPP + 2 + 7) / 8;  // moves per slot: 2 for the 10-type shape (12 moves over 8 slots), 3 for the 16-type one
             const int j = tid >> 3, slot = tid & 7;
             int m_off[MS], m_key[MS], m_plb[MS];
             bool m_ok[MS], m_del[MS];

@@ -158,6 +158,8 @@ class Context:
         self.h = h
         self.torch = torch
         self.tdev = torch.device("cuda", self.device)
+        self.pipeline = False
+        self._held = []   # batches whose device work the pipeline may still hold back: kept alive until the next flush
 
     def use_current_stream(self):
         self.lib.svx_set_stream(self.h, c_vp(self.torch.cuda.current_stream(self.tdev).cuda_stream))
@@ -171,14 +173,29 @@ class Context:
 
     def sync(self):
         self.check(self.lib.svx_synchronize(self.h))
+        del self._held[:]
 
     def set_pipeline(self, on):
         """Software pipeline over consecutive svx_align_batch calls (include/svx.h: svx_set_pipeline); while it is on,
         outputs are complete only after flush() / sync()."""
         self.check(self.lib.svx_set_pipeline(self.h, 1 if on else 0))
+        self.pipeline = bool(on)
+        del self._held[:]   # (switching flushes)
 
     def flush(self):
         self.check(self.lib.svx_flush(self.h))
+        # everything the pipeline held back is now ordered in front of whatever follows on the current stream, so memory
+        # released from here on is reused behind it
+        del self._held[:]
+
+    def hold(self, batch):
+        """The pipeline reads a batch's tensors on internal streams the tensor library knows nothing about, possibly
+        during the NEXT call: keep the last few batches alive until a flush."""
+        if self.pipeline:
+            self._held.append(batch)
+            if len(self._held) > 4:
+                self.flush()
+                self._held.append(batch)
 
     def __del__(self):
         try:

@@ -270,6 +270,7 @@ class PreparedBatch:
         ctx = self.ctx
         ctx.use_current_stream()
         ctx.check(ctx.lib.svx_align_batch(ctx.h, ctypes.byref(self.prm), self.cpairs, len(self.vecs)))
+        ctx.hold(self)
 
     def flush(self):
         """With the context's pipeline on (Context.set_pipeline): launch what run() held back and order it in front of
