@@ -191,11 +191,10 @@ class Context:
     def hold(self, batch):
         """The pipeline reads a batch's tensors on internal streams the tensor library knows nothing about, possibly
         during the NEXT call: keep the last few batches alive until a flush."""
-        if self.pipeline:
-            self._held.append(batch)
-            if len(self._held) > 4:
+        if self.pipeline and not any(b is batch for b in self._held):   # (a batch that is run again and again counts once)
+            if len(self._held) >= 4:
                 self.flush()
-                self._held.append(batch)
+            self._held.append(batch)
 
     def __del__(self):
         try:
