@@ -410,7 +410,7 @@ def main():
         return cpu_worker(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=10)   # (the pipeline fills in the first step and drains after the last: amortised over the run)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "dense"])
     ap.add_argument("--band", type=int, default=2048, help="c4: band width (cells per diagonal) around the straight diagonal")

@@ -160,6 +160,8 @@ class Context:
         self.tdev = torch.device("cuda", self.device)
         self.pipeline = False
         self._held = []   # batches whose device work the pipeline may still hold back: kept alive until the next flush
+        if os.environ.get("SVX_PIPELINE") == "1":   # default for this process (the GPU suite is also run once this way)
+            self.set_pipeline(True)
 
     def use_current_stream(self):
         self.lib.svx_set_stream(self.h, c_vp(self.torch.cuda.current_stream(self.tdev).cuda_stream))
