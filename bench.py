@@ -466,7 +466,7 @@ def extra_workloads(args):
             legs[name]["leg_seconds"] = time.perf_counter() - t
         except Exception as e:  # never lose the headline line to a side leg
             legs[name] = {"error": repr(e)}
-    leg("c3", workload="c3", pairs=1024, steps=2, warmup=1)
+    leg("c3", workload="c3", pairs=1024, steps=5, warmup=1)
     leg("c4_1pair", workload="c4", pairs=1, steps=2, warmup=1)
     leg("c4_4pairs", workload="c4", pairs=4, steps=2, warmup=1)
     leg("c4_8pairs", workload="c4", pairs=8, steps=1, warmup=1)

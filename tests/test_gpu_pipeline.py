@@ -167,6 +167,23 @@ def test_pipeline_does_not_change_results():
         piped = sequence()
     finally:
         ctx.set_pipeline(False)
+    # svx_flush orders the held-back work in front of whatever follows ON THE STREAM: a device-side copy queued behind
+    # the flush, without any host synchronisation in between, already sees the final rows of the held-back half
+    import torch
+    pb = dp_utils.PreparedBatch(many, types, 0.2, 7, 300, 20000, 100, rngs=[np.random.RandomState(400 + i) for i in range(len(many))])
+    try:
+        ctx.set_pipeline(True)
+        pb.align.zero_()
+        pb.info.zero_()
+        pb.run()
+        pb.flush()
+        rows_after_flush, info_after_flush = pb.align.clone(), pb.info.clone()
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_pipeline(False)
+    assert np.array_equal(info_after_flush.cpu().numpy(), pb.raw_results()[0])
+    assert np.array_equal(rows_after_flush.cpu().numpy(), pb.raw_results()[1])
+    assert [r[0] for r in pb.results()] == [r[0] for r in plain[3]]
     for o, q in zip(plain[:4], piped[:4]):
         assert len(o) == len(q)
         for x, y in zip(o, q):
