@@ -1020,7 +1020,7 @@ static int run_interleaved(svx_ctx* ctx, HalfState* front, HalfState* chain, boo
         if (!segs[g].has_s) break;
         // cover the group with front kernels before the streaming kernel that waits for it
         double acc = 0.0;
-        need = need * 1.25 + 50.0;
+        need = need * 1.25 + 50.0;   // (1.6, 2.0, 2.6: the same step time)
         while (beside && fi < fops.size() && acc < need) {
             if ((rc = run_op(ctx, fops[fi], A))) return rc;
             acc += fops[fi].us;

@@ -270,6 +270,16 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
     constexpr int RPWV = 2 * (SVX_PYR_SLOTS / 4);
     static_assert(RPWV % DEPTH == 0, "whole ring revolutions");
     const int rl = r1 - 1;   // last row of this wave
+    // this lane's elements of mean and rbar stay in registers for the wave's 16 rows (re-read from LDS for every row they
+    // cost 8 ds_read_b128 per row and their waits: levels >= 2 19.2 -> 18.5 ms, level 1 21.6 -> 21.3 ms per 1024 pairs; three
+    // workgroups per CU instead of four is what the row walk needs to stream, profiles/micro/row_stream.hip)
+    // (wider rows -- 32 elements per lane -- keep reading them from LDS: the registers are not there)
+    constexpr bool HOIST = EPL <= 16;
+    float mu[EPL], rbv[EPL];
+    if (HOIST) {
+        lane_major(mu_l, mu);
+        lane_major(rb_l, rbv);
+    }
     if (r0 < r1) {           // wave-uniform
 #pragma unroll
         for (int s = 0; s < DEPTH; s++) fetch_raw<E, NCH, PAIR, NT, FULL>(rows, inv0, (r0 + s) < rl ? (r0 + s) : rl, d, lane, ring[s]);
@@ -282,8 +292,7 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
             if (i + DEPTH < RPWV) fetch_raw<E, NCH, PAIR, NT, FULL>(rows, inv0, (r + DEPTH) < rl ? (r + DEPTH) : rl, d, lane, ring[s]);
             if (r >= r1) continue;  // wave-uniform (a partial wave at the end of a layer)
             if (mean) {
-                float mu[EPL];
-                lane_major(mu_l, mu);
+                if (!HOIST) lane_major(mu_l, mu);
 #pragma unroll
                 for (int e = 0; e < EPL; e++) x[e] = x[e] - mu[e];  // columns >= d: 0 - 0
             }
@@ -296,8 +305,7 @@ __device__ void pyr_block(const typename E::storage* rows, int n, int d, const f
 #pragma unroll
             for (int e = 0; e < EPL; e++) x[e] = x[e] * rden;
             if (rbar) {
-                float rbv[EPL];
-                lane_major(rb_l, rbv);
+                if (!HOIST) lane_major(rb_l, rbv);
                 float dt = 0.f;
 #pragma unroll
                 for (int e = 0; e < EPL; e++) dt += x[e] * rbv[e];
