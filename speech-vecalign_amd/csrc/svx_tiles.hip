@@ -472,41 +472,58 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
                 m_del[m] = !(t < T);                           // a deletion costs `pen`
                 m_plb[m] = t < T ? t * TL * TL : 0;            // cost plane of the move (any plane for the others: value unused)
             }
+            // Loop invariants of this thread's node column j, and the band offsets of the tile's 63 diagonals (a = 32 (I + J) + dd
+            // for every node of diagonal dd) one per lane, fetched by v_readlane in the loop: the loop body is instruction-bound
+            // (~180 instructions per diagonal with the offsets read from LDS behind a branch and short-circuit merges; ~120 so).
+            const int yy = TL * J + j;
+            const bool y_in = yy <= ys, y_pos = yy >= 1;
+            const int xrel_max = xs - TL * I;                  // node rows of the tile that exist: ic <= xrel_max
+            const int a0 = TL * (I + J);
+            const int bo_mine = bo_l[a0 + (tid & 63) - abase]; // (lane 63: one past the tile's last diagonal, never selected; inside bo_l)
+            const bool edge_tile = I == 0 || J == 0;           // only these tiles hold nodes of row 0 / column 0
+            double cconst[MS];
+            bool use_cv[MS];
+#pragma unroll
+            for (int m = 0; m < MS; m++) {
+                use_cv[m] = m_ok[m] && !m_del[m];
+                cconst[m] = m_ok[m] ? pen : inf;               // a move this slot does not have can never win
+                if (!m_ok[m]) m_off[m] = 0;                    // (its csum read is any valid cell)
+            }
             for (int dd = 0; dd <= 2 * (TL - 1); dd++) {
                 const int i = dd - j;
-                const bool inside = i >= 0 && i < TL;
+                const bool inside = (unsigned)i < (unsigned)TL;
                 const int ic = inside ? i : 0;
-                const int xx = TL * I + ic, yy = TL * J + j;
-                const int a = xx + yy;
                 const int cpos = (ic + TT_HALO) * CS_W + (j + TT_HALO), ppos = ic * TL + j;
-                const int bo = bo_l[a - abase];
                 double pv[MS];
                 float cv[MS];
 #pragma unroll
                 for (int m = 0; m < MS; m++) {
-                    pv[m] = cs[m_ok[m] ? cpos + m_off[m] : CS_W * CS_W];
+                    pv[m] = cs[cpos + m_off[m]];
                     cv[m] = planes[m_plb[m] + ppos];
+                    asm volatile("" : "+v"(cv[m]));   // (every read issued here, none sunk into a branch behind its own wait)
                 }
+                const int bo = __builtin_amdgcn_readlane(bo_mine, dd);
                 const int b = yy - bo;
-                const bool node = inside && xx <= xs && yy <= ys && b >= 0 && b < B;
-                const bool general = node && xx >= 1 && yy >= 1 && (a - 2) < A;
+                const bool node = inside & (ic <= xrel_max) & y_in & (b >= 0) & (b < B);
+                const bool general = node & (TL * I + ic >= 1) & y_pos & (a0 + dd - 2 < A);
                 DpMerge best{inf, 0x7fffffff};
 #pragma unroll
                 for (int m = 0; m < MS; m++) {
-                    const double tot = pv[m] + (m_del[m] ? pen : (double)cv[m]);
+                    const double tot = pv[m] + (use_cv[m] ? (double)cv[m] : cconst[m]);
                     const bool take = tot < best.tot;
                     best.tot = take ? tot : best.tot;
                     best.key = take ? m_key[m] : best.key;
                 }
-                // merge over the node's eight lanes: lane ^ 1, lane ^ 2 (quad permutes), then the other quad (half-row mirror)
+                // merge over the node's eight lanes: lane ^ 1, lane ^ 2 (quad permutes), then the other quad (half-row mirror);
+                // (total, move index) order without a short-circuit branch
 #define TILE_MERGE(CTRL)                                                                                                      \
     {                                                                                                                         \
         const unsigned long long u_ = __double_as_longlong(best.tot);                                                         \
-        const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u_, CTRL, 0xf, 0xf, false);               \
-        const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u_ >> 32), CTRL, 0xf, 0xf, false);       \
-        const int ok_ = __builtin_amdgcn_update_dpp(0, best.key, CTRL, 0xf, 0xf, false);                                       \
+        const unsigned lo_ = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u_, CTRL, 0xf, 0xf, true);                      \
+        const unsigned hi_ = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u_ >> 32), CTRL, 0xf, 0xf, true);              \
+        const int ok_ = __builtin_amdgcn_mov_dpp(best.key, CTRL, 0xf, 0xf, true);   /* (every lane has a source: no old value) */ \
         const double ot_ = __longlong_as_double(((unsigned long long)hi_ << 32) | lo_);                                       \
-        const bool tk_ = ot_ < best.tot || (ot_ == best.tot && ok_ < best.key);                                               \
+        const bool tk_ = (ot_ < best.tot) | ((ot_ == best.tot) & (ok_ < best.key));                                           \
         best.tot = tk_ ? ot_ : best.tot;                                                                                      \
         best.key = tk_ ? ok_ : best.key;                                                                                      \
     }
@@ -514,14 +531,17 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
                 TILE_MERGE(0x4E)   // quad_perm [2,3,0,1]
                 TILE_MERGE(0x141)  // row_half_mirror: lane k of an 8-lane group <-> lane 7 - k (the other quad)
 #undef TILE_MERGE
-                if (!general) { best.tot = inf; best.key = 0x7fffffff; }
-                double v = best.key != 0x7fffffff ? best.tot : inf;
-                int bx = best.key != 0x7fffffff ? (best.key & 255) : -1, by = best.key != 0x7fffffff ? ((best.key >> 8) & 255) : -1;
-                if (node && xx == 0) { v = pen * (double)yy; bx = 0; by = 1; }
-                else if (node && yy == 0) { v = pen * (double)xx; bx = 1; by = 0; }
+                const bool won = general & (best.key != 0x7fffffff);
+                double v = won ? best.tot : inf;
+                int bpv = won ? (((best.key & 255) << 4) | ((best.key >> 8) & 255)) : 0xFF;
+                if (edge_tile) {   // workgroup-uniform
+                    const int xx = TL * I + ic;
+                    if (node && xx == 0) { v = pen * (double)yy; bpv = (0 << 4) | 1; }
+                    else if (node && yy == 0) { v = pen * (double)xx; bpv = (1 << 4) | 0; }
+                }
                 if (inside && slot == 0) {
                     cs[cpos] = node ? v : inf;
-                    bpt[ppos] = (!node || bx < 0) ? (unsigned char)0xFF : (unsigned char)((bx << 4) | by);
+                    bpt[ppos] = (unsigned char)(node ? bpv : 0xFF);
                 }
                 __syncthreads();   // the diagonal is complete before any wave reads it
             }
