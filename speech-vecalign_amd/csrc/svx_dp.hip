@@ -739,7 +739,8 @@ __device__ void sparse_traceback_block(const TbArgs& g, char* smem) {
     const bool cor = g.cw > 0;
     const size_t win_bytes = g.chunk > 0 ? (cor ? tb_win_bytes(g.chunk, g.cw, false) : tb_win_bytes(g.chunk, B, wide)) : 0;
     const int nwin = g.chunk > 0 ? (Aout + g.chunk - 1) / g.chunk : 1;
-    int xx = g.xs, yy = g.ys, nw = 0, err = 0;  // walk state of thread 0
+    int xx = __builtin_amdgcn_readfirstlane(g.xs), yy = __builtin_amdgcn_readfirstlane(g.ys), nw = 0, err = 0;  // walk state (wave-uniform: scalar registers)
+    const bool wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;   // (a branch the compiler knows to be wave-uniform)
     bool done = false;
     if (g.chunk > 0) {
         if (cor) {
@@ -770,52 +771,64 @@ __device__ void sparse_traceback_block(const TbArgs& g, char* smem) {
             __syncthreads();
             if (threadIdx.x >= 64) tb_load_corridor(g, smem + (size_t)((j - 1) & 1) * win_bytes, j - 1, sh_c0[(j - 1) & 1], threadIdx.x - 64, blockDim.x - 64);
         } else if (g.chunk > 0 && j > 0 && threadIdx.x >= 64) tb_load_window(g, smem + (size_t)((j - 1) & 1) * win_bytes, j - 1, threadIdx.x - 64, blockDim.x - 64);
-        if (threadIdx.x == 0 && !done && !err) {
+        // The walk runs on the whole first wave with every value it reads made wave-uniform (v_readfirstlane): its state
+        // (xx, yy, the band column, the counters) then lives in scalar registers and the step's tests are scalar branches
+        // instead of exec-mask juggling on a single lane: 0.26 -> 0.21 us per step.  What bounds a step now is the issue rate
+        // of ONE wave (an instruction every four cycles at best, ~60 per step), not its two LDS reads: fetching the band
+        // offsets 64 at a time (one per lane, picked by v_readlane) to save one of them changed nothing.
+        if (wave0 && !done && !err) {
             const int lo = g.chunk > 0 ? j * g.chunk : 0;
             const char* win = smem + (size_t)(j & 1) * win_bytes;
             const unsigned char* lbp = reinterpret_cast<const unsigned char*>(win);
             const unsigned short* lbw = reinterpret_cast<const unsigned short*>(win);
             const int* lbo = reinterpret_cast<const int*>(win + ((((size_t)g.chunk * (cor ? g.cw : B) * ((wide && !cor) ? 2 : 1)) + 15) & ~(size_t)15));
-            const int c0w = cor ? sh_c0[j & 1] : 0;
+            const int c0w = cor ? __builtin_amdgcn_readfirstlane(sh_c0[j & 1]) : 0;
+            const bool lane0 = threadIdx.x == 0;
             for (;;) {
+                xx = __builtin_amdgcn_readfirstlane(xx);   // (said again every step: the compiler keeps the loop-carried copies in
+                yy = __builtin_amdgcn_readfirstlane(yy);   //  vector registers otherwise, and the whole step with them)
+                nw = __builtin_amdgcn_readfirstlane(nw);
                 if (xx == 0 && yy == 0) { done = true; break; }
                 const int aa = xx + yy;
                 if (aa < lo) break;  // continues in the next window
                 if (aa < 0 || aa >= Aout || nw >= cap - 1) { err = SVX_ERR_TRACEBACK; break; }
-                const int bb = yy - (g.chunk > 0 ? lbo[aa - lo] : g.boff[aa]);
+                int bo_a;
+                if (g.chunk > 0) bo_a = lbo[aa - lo];
+                else bo_a = g.boff[aa];
+                const int bb = yy - __builtin_amdgcn_readfirstlane(bo_a);
                 if (bb < 0 || bb >= B) { err = SVX_ERR_TRACEBACK; break; }
                 int px, py;
                 if (cor) {
                     const int cc = bb - c0w;
-                    const unsigned char v = (cc >= 0 && cc < g.cw) ? lbp[(size_t)(aa - lo) * g.cw + cc] : gld(g.bpk + (size_t)aa * B + bb);
+                    const int v = __builtin_amdgcn_readfirstlane((int)((cc >= 0 && cc < g.cw) ? lbp[(size_t)(aa - lo) * g.cw + cc] : gld(g.bpk + (size_t)aa * B + bb)));
                     px = v == 0xFF ? -42 : (v >> 4);
                     py = v == 0xFF ? -42 : (v & 15);
                 } else if (g.chunk > 0) {
                     const size_t o = (size_t)(aa - lo) * B + bb;
                     if (!wide) {
-                        const unsigned char v = lbp[o];
+                        const int v = __builtin_amdgcn_readfirstlane((int)lbp[o]);
                         px = v == 0xFF ? -42 : (v >> 4);
                         py = v == 0xFF ? -42 : (v & 15);
                     } else {
-                        const unsigned short v = lbw[o];
+                        const int v = __builtin_amdgcn_readfirstlane((int)lbw[o]);
                         px = v == 0xFFFF ? -42 : (v >> 8);
                         py = v == 0xFFFF ? -42 : (v & 255);
                     }
                 } else {
                     const size_t o = (size_t)aa * B + bb;
                     if (g.bpk) {
-                        const unsigned char v = g.bpk[o];
+                        const int v = __builtin_amdgcn_readfirstlane((int)g.bpk[o]);
                         px = v == 0xFF ? -42 : (v >> 4);
                         py = v == 0xFF ? -42 : (v & 15);
                     } else {
-                        px = g.xp[o];
-                        py = g.yp[o];
+                        px = __builtin_amdgcn_readfirstlane(g.xp[o]);
+                        py = __builtin_amdgcn_readfirstlane(g.yp[o]);
                     }
                 }
                 if (px < 0 || py < 0 || (px == 0 && py == 0) || px > xx || py > yy) { err = SVX_ERR_TRACEBACK; break; }
                 // (a global store: a flat one would also count against lgkmcnt, and the next step's LDS reads would wait for
                 //  its write acknowledgement -- one memory round trip per step of the walk)
-                gst16(g.align + 4 * (size_t)(cap - 1 - nw), (uint32_t)(xx - px), (uint32_t)px, (uint32_t)(yy - py), (uint32_t)py);
+                if (lane0) gst16(g.align + 4 * (size_t)(cap - 1 - nw), (uint32_t)(xx - px), (uint32_t)px, (uint32_t)(yy - py), (uint32_t)py);
                 xx -= px;
                 yy -= py;
                 nw++;
