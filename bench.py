@@ -382,6 +382,7 @@ def bench_straight(args):
            "roofline": {"bound": "mfma", "kernel": "k_band_tiles (cost tiles + DP wavefront)", "stage": "tiles",
                         "achieved": flops * P / (tile_ms * 1e-3) / 1e12 if tile_ms > 0 else None, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac": (flops * P / (tile_ms * 1e-3) / 1e12 / 2500.0) if tile_ms > 0 else None, "traffic": None,
+                        "traffic_source": "no counter pass committed for this mode (the tile sweep re-reads its rows out of L2: DESIGN.md section 6)",
                         "avg_launch_ms": tile_ms, "algorithmic_flops_per_launch": flops * P,
                         "note": "the sweep is bound by the serial chain of tile anti-diagonals (%d of them) and the float64 DP inside a tile, "
                                 "not by the matrix cores" % ((N // 32 + 1) + (M // 32 + 1) - 1)}}
@@ -655,6 +656,8 @@ def bench_ctf(args):
                         break
                 except Exception:
                     pass
+            if traffic is None:
+                traffic_note = "no committed counter pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) at this workload / pairs per step: traffic is null, not zero"
             rl = {"bound": "hbm", "kernel": STAGE_KERNEL.get(dom, dom), "stage": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_note,
                   "avg_launch_ms": avg_ms, "launches_per_step": launches / args.steps, "pairs_per_launch": pairs_per_launch,
