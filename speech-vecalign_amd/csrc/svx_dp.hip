@@ -730,6 +730,80 @@ __device__ __forceinline__ void tb_load_window(const TbArgs& g, char* win, int j
 // Thread 0 walks the back-pointers from (xs,ys) to (0,0) and writes the alignment rows from the back of the
 // buffer.  The walk only ever moves to smaller diagonals, so the back-pointers pass through LDS as a sliding
 // pair of windows: while thread 0 walks window j the other waves fetch window j-1.
+// One window's share of the back-pointer walk, on the first wave with wave-uniform state (see sparse_traceback_block).
+// MODE 0: no LDS window (back-pointers and band offsets from global memory), 1: packed bytes in the window, 2: 16-bit pairs in
+// the window, 3: corridor window (packed bytes, cw columns from column c0w; outside it: global memory).
+template <int MODE>
+__device__ __forceinline__ void tb_walk(const TbArgs& g, const unsigned char* lbp, const unsigned short* lbw, const int* lbo, int lo, int c0w,
+                                        int cap, int& xx, int& yy, int& nw, int& err, bool& done) {
+    const int Aout = g.Aout, B = g.B;
+    // The rows the walk produces wait in the lanes (row number nw in lane nw & 63, one compare and four selects per step) and leave 64 at a
+    // time, one 16-byte store per lane, instead of as one masked store with its address arithmetic on every step.
+    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    int first_pending = __builtin_amdgcn_readfirstlane(nw);
+    auto flush = [&](int first, int last) {   // rows [first, last), all inside one block of 64
+        const int idx = (first & ~63) + (int)threadIdx.x;
+        if (idx >= first && idx < last) gst16(g.align + 4 * (size_t)(cap - 1 - idx), (uint32_t)r0, (uint32_t)r1, (uint32_t)r2, (uint32_t)r3);
+    };
+    for (;;) {
+        xx = __builtin_amdgcn_readfirstlane(xx);   // (said again every step: the compiler keeps the loop-carried copies in
+        yy = __builtin_amdgcn_readfirstlane(yy);   //  vector registers otherwise, and the whole step with them)
+        nw = __builtin_amdgcn_readfirstlane(nw);
+        if (xx == 0 && yy == 0) { done = true; break; }
+        const int aa = xx + yy;
+        if (aa < lo) break;  // continues in the next window
+        if (aa < 0 || aa >= Aout || nw >= cap - 1) { err = SVX_ERR_TRACEBACK; break; }
+        int bo_a;
+        if (MODE != 0) bo_a = lbo[aa - lo];
+        else bo_a = g.boff[aa];
+        const int bb = yy - __builtin_amdgcn_readfirstlane(bo_a);
+        if (bb < 0 || bb >= B) { err = SVX_ERR_TRACEBACK; break; }
+        int px, py;
+        if (MODE == 3) {
+            const int cc = bb - c0w;
+            const int v = __builtin_amdgcn_readfirstlane((int)((cc >= 0 && cc < g.cw) ? lbp[(size_t)(aa - lo) * g.cw + cc] : gld(g.bpk + (size_t)aa * B + bb)));
+            px = v == 0xFF ? -42 : (v >> 4);
+            py = v == 0xFF ? -42 : (v & 15);
+        } else if (MODE == 1) {
+            const int v = __builtin_amdgcn_readfirstlane((int)lbp[(size_t)(aa - lo) * B + bb]);
+            px = v == 0xFF ? -42 : (v >> 4);
+            py = v == 0xFF ? -42 : (v & 15);
+        } else if (MODE == 2) {
+            const int v = __builtin_amdgcn_readfirstlane((int)lbw[(size_t)(aa - lo) * B + bb]);
+            px = v == 0xFFFF ? -42 : (v >> 8);
+            py = v == 0xFFFF ? -42 : (v & 255);
+        } else {
+            const size_t o = (size_t)aa * B + bb;
+            if (g.bpk) {
+                const int v = __builtin_amdgcn_readfirstlane((int)g.bpk[o]);
+                px = v == 0xFF ? -42 : (v >> 4);
+                py = v == 0xFF ? -42 : (v & 15);
+            } else {
+                px = __builtin_amdgcn_readfirstlane(g.xp[o]);
+                py = __builtin_amdgcn_readfirstlane(g.yp[o]);
+            }
+        }
+        if (px < 0 || py < 0 || (px == 0 && py == 0) || px > xx || py > yy) { err = SVX_ERR_TRACEBACK; break; }
+        const int ln = nw & 63;
+        {
+            const bool me = (int)threadIdx.x == ln;
+            r0 = me ? xx - px : r0;
+            r1 = me ? px : r1;
+            r2 = me ? yy - py : r2;
+            r3 = me ? py : r3;
+        }
+        xx -= px;
+        yy -= py;
+        nw++;
+        if ((nw & 63) == 0) {   // (global stores, not flat ones: a flat store would count against lgkmcnt and the next step's LDS
+            flush(first_pending, nw);   //  reads would wait for its acknowledgement)
+            first_pending = nw;
+        }
+    }
+    nw = __builtin_amdgcn_readfirstlane(nw);
+    if (first_pending < nw) flush(first_pending, nw);
+}
+
 __device__ void sparse_traceback_block(const TbArgs& g, char* smem) {
     __shared__ int sh_n;
     __shared__ int sh_c0[2];   // corridor windows: first column of the window in buffer 0 / 1
@@ -783,56 +857,11 @@ __device__ void sparse_traceback_block(const TbArgs& g, char* smem) {
             const unsigned short* lbw = reinterpret_cast<const unsigned short*>(win);
             const int* lbo = reinterpret_cast<const int*>(win + ((((size_t)g.chunk * (cor ? g.cw : B) * ((wide && !cor) ? 2 : 1)) + 15) & ~(size_t)15));
             const int c0w = cor ? __builtin_amdgcn_readfirstlane(sh_c0[j & 1]) : 0;
-            const bool lane0 = threadIdx.x == 0;
-            for (;;) {
-                xx = __builtin_amdgcn_readfirstlane(xx);   // (said again every step: the compiler keeps the loop-carried copies in
-                yy = __builtin_amdgcn_readfirstlane(yy);   //  vector registers otherwise, and the whole step with them)
-                nw = __builtin_amdgcn_readfirstlane(nw);
-                if (xx == 0 && yy == 0) { done = true; break; }
-                const int aa = xx + yy;
-                if (aa < lo) break;  // continues in the next window
-                if (aa < 0 || aa >= Aout || nw >= cap - 1) { err = SVX_ERR_TRACEBACK; break; }
-                int bo_a;
-                if (g.chunk > 0) bo_a = lbo[aa - lo];
-                else bo_a = g.boff[aa];
-                const int bb = yy - __builtin_amdgcn_readfirstlane(bo_a);
-                if (bb < 0 || bb >= B) { err = SVX_ERR_TRACEBACK; break; }
-                int px, py;
-                if (cor) {
-                    const int cc = bb - c0w;
-                    const int v = __builtin_amdgcn_readfirstlane((int)((cc >= 0 && cc < g.cw) ? lbp[(size_t)(aa - lo) * g.cw + cc] : gld(g.bpk + (size_t)aa * B + bb)));
-                    px = v == 0xFF ? -42 : (v >> 4);
-                    py = v == 0xFF ? -42 : (v & 15);
-                } else if (g.chunk > 0) {
-                    const size_t o = (size_t)(aa - lo) * B + bb;
-                    if (!wide) {
-                        const int v = __builtin_amdgcn_readfirstlane((int)lbp[o]);
-                        px = v == 0xFF ? -42 : (v >> 4);
-                        py = v == 0xFF ? -42 : (v & 15);
-                    } else {
-                        const int v = __builtin_amdgcn_readfirstlane((int)lbw[o]);
-                        px = v == 0xFFFF ? -42 : (v >> 8);
-                        py = v == 0xFFFF ? -42 : (v & 255);
-                    }
-                } else {
-                    const size_t o = (size_t)aa * B + bb;
-                    if (g.bpk) {
-                        const int v = __builtin_amdgcn_readfirstlane((int)g.bpk[o]);
-                        px = v == 0xFF ? -42 : (v >> 4);
-                        py = v == 0xFF ? -42 : (v & 15);
-                    } else {
-                        px = __builtin_amdgcn_readfirstlane(g.xp[o]);
-                        py = __builtin_amdgcn_readfirstlane(g.yp[o]);
-                    }
-                }
-                if (px < 0 || py < 0 || (px == 0 && py == 0) || px > xx || py > yy) { err = SVX_ERR_TRACEBACK; break; }
-                // (a global store: a flat one would also count against lgkmcnt, and the next step's LDS reads would wait for
-                //  its write acknowledgement -- one memory round trip per step of the walk)
-                if (lane0) gst16(g.align + 4 * (size_t)(cap - 1 - nw), (uint32_t)(xx - px), (uint32_t)px, (uint32_t)(yy - py), (uint32_t)py);
-                xx -= px;
-                yy -= py;
-                nw++;
-            }
+            // (one copy of the walk per storage mode: the mode tests would otherwise be re-evaluated on every step)
+            if (cor) tb_walk<3>(g, lbp, lbw, lbo, lo, c0w, cap, xx, yy, nw, err, done);
+            else if (g.chunk > 0 && !wide) tb_walk<1>(g, lbp, lbw, lbo, lo, c0w, cap, xx, yy, nw, err, done);
+            else if (g.chunk > 0) tb_walk<2>(g, lbp, lbw, lbo, lo, c0w, cap, xx, yy, nw, err, done);
+            else tb_walk<0>(g, lbp, lbw, lbo, lo, c0w, cap, xx, yy, nw, err, done);
         }
         if (g.chunk > 0) __syncthreads();
     }
