@@ -560,3 +560,26 @@ def test_straight_narrow_band_vs_oracle(orc):
     al_g, sc_g = dp_utils.align_band(v0, v1, types, 0.2, W, 20000, 100)
     assert al_g == al_o
     assert np.abs(sc_g - sc_o).max() < SCORE_TOL
+
+
+@pytest.mark.parametrize("m2o", [None, 20])
+def test_band_too_wide_for_the_traceback_window_vs_oracle(orc, m2o):
+    """A band of 400 cells per diagonal leaves no room for a traceback window in LDS (tb_chunk() == 0): the walk then
+    reads band offsets and back-pointers from global memory -- packed bytes for the 10-type shape, int32 pairs when the
+    steps do not fit four bits (--many_to_one 20).  Same spans and scores as the oracle."""
+    from svx.vecalign import dp_utils
+    from svx.vecalign.vecalign import resolve_search_params
+    W = 200
+    if m2o is None:
+        types = alignment_types(5)
+        v0, v1 = make_pair(310, 280, 4, 64, 91, deletions=7)
+    else:
+        types, sk, tk, _ = resolve_search_params(10, m2o, 5)
+        v0, v1 = make_pair(330, 90, m2o, 64, 92)
+        v1 = np.ascontiguousarray(v1[:1])
+    np.random.seed(17)
+    ref = orc.vecalign(v0.copy(), v1.copy(), types, 0.2, W, 300, 20000, 100)
+    np.random.seed(17)
+    got = dp_utils.vecalign(v0, v1, types, 0.2, W, 300, 20000, 100)
+    assert got[0]['final_alignments'] == ref[0]['final_alignments']
+    assert np.abs(got[0]['alignment_scores'] - ref[0]['alignment_scores']).max() < SCORE_TOL
