@@ -852,20 +852,27 @@ static void front_ops(svx_ctx* ctx, HalfState& H, std::vector<Op>& ops, int spli
             }
             ops.push_back({H.b_pyr[l] / (l == 0 ? 4.9e6 : 5.3e6) / parts, l == 0 ? S_PYR0 : (l == 1 ? S_PYR1 : S_PYRN), [=]() -> int {
                 hipStream_t main_stream = ctx->stream;
-                // the slice's helpers: helper stream, behind the slice's pass of the level above
-                if (l > 0) SVX_HIP(ctx, hipStreamWaitEvent(cx->helper, evs->pass[l - 1][q], 0));
-                ctx->stream = cx->helper;
                 int rc;
-                {
+                if (l == 0 && q == 0) {
+                    // the front's very first helper has nothing to hide behind: on the context's stream itself (two
+                    // cross-stream hand-offs, ~0.2 ms, off the start of every half-batch)
                     StageScope sc(ctx, S_PYR_AUX);
-                    rc = svxl_pyramid_level(ctx, h->dpairs + lo, hi - lo, l, dtype, d, h->max_nblk[l], h->max_ksum, 0);
+                    if ((rc = svxl_pyramid_level(ctx, h->dpairs + lo, hi - lo, l, dtype, d, h->max_nblk[l], h->max_ksum, 0))) return rc;
+                } else {
+                    // the slice's helpers: helper stream, behind the slice's pass of the level above
+                    if (l > 0) SVX_HIP(ctx, hipStreamWaitEvent(cx->helper, evs->pass[l - 1][q], 0));
+                    ctx->stream = cx->helper;
+                    {
+                        StageScope sc(ctx, S_PYR_AUX);
+                        rc = svxl_pyramid_level(ctx, h->dpairs + lo, hi - lo, l, dtype, d, h->max_nblk[l], h->max_ksum, 0);
+                    }
+                    ctx->stream = main_stream;
+                    if (rc) return rc;
+                    hipEvent_t aux_done;
+                    if ((rc = next_event(ctx, &aux_done))) return rc;
+                    SVX_HIP(ctx, hipEventRecord(aux_done, cx->helper));
+                    SVX_HIP(ctx, hipStreamWaitEvent(main_stream, aux_done, 0));
                 }
-                ctx->stream = main_stream;
-                if (rc) return rc;
-                hipEvent_t aux_done;
-                if ((rc = next_event(ctx, &aux_done))) return rc;
-                SVX_HIP(ctx, hipEventRecord(aux_done, cx->helper));
-                SVX_HIP(ctx, hipStreamWaitEvent(main_stream, aux_done, 0));
                 if ((rc = svxl_pyramid_level(ctx, h->dpairs + lo, hi - lo, l, dtype, d, h->max_nblk[l], h->max_ksum, 1))) return rc;
                 if ((rc = next_event(ctx, &evs->pass[l][q]))) return rc;
                 SVX_HIP(ctx, hipEventRecord(evs->pass[l][q], main_stream));
