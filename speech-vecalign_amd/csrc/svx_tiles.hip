@@ -504,11 +504,12 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
                 }
                 const int bo = __builtin_amdgcn_readlane(bo_mine, dd);
                 const int b = yy - bo;
-                const bool node = inside & (ic <= xrel_max) & y_in & (b >= 0) & (b < B);
+                const bool node = inside & (ic <= xrel_max) & y_in & ((unsigned)b < (unsigned)B);
                 const bool general = node & (TL * I + ic >= 1) & y_pos & (a0 + dd - 2 < A);
-                DpMerge best{inf, 0x7fffffff};
+                // (the slot's first move starts the minimum; "no move reaches this node" is read off the total at the end)
+                DpMerge best{pv[0] + (use_cv[0] ? (double)cv[0] : cconst[0]), m_key[0]};
 #pragma unroll
-                for (int m = 0; m < MS; m++) {
+                for (int m = 1; m < MS; m++) {
                     const double tot = pv[m] + (use_cv[m] ? (double)cv[m] : cconst[m]);
                     const bool take = tot < best.tot;
                     best.tot = take ? tot : best.tot;
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_band_tiles(const SvxPairDev* __r
                 TILE_MERGE(0x4E)   // quad_perm [2,3,0,1]
                 TILE_MERGE(0x141)  // row_half_mirror: lane k of an 8-lane group <-> lane 7 - k (the other quad)
 #undef TILE_MERGE
-                const bool won = general & (best.key != 0x7fffffff);
+                const bool won = general & (best.tot < inf);
                 double v = won ? best.tot : inf;
                 int bpv = won ? (((best.key & 255) << 4) | ((best.key >> 8) & 255)) : 0xFF;
                 if (edge_tile) {   // workgroup-uniform
